@@ -1,0 +1,88 @@
+/*
+ * dvt_prover.h — C ABI of the MI355X-native STARK prover that replaces the SP1
+ * prover behind metacraft-labs/dvt-circuits' prove()/execute() boundary.
+ *
+ * The reference reaches its prover through six call sites in src/main.rs
+ * (ProverClient::from_env :438,:461,:481; setup :462,:482; prove(..).run()
+ * :463-466; execute(..).run() :439-442,:498-501; SP1Stdin::write :434-437,
+ * :458-460; proof.save :472-474).  Each entry point below names the call site
+ * it stands in for.  INTEGRATION.md shows the Rust `extern "C"` stub a
+ * maintainer would add.
+ *
+ * Conventions
+ *   - return 0 = ok; DVT_ERR_GUEST = guest halted non-zero / panicked (what the
+ *     reference's 92 test vectors observe as process exit code 1, script/run.sh:82-89);
+ *     DVT_ERR_INPUT = malformed argument / ELF / proof; DVT_ERR_DEVICE = HIP failure
+ *     or no gfx950 device (there is NO CPU fallback); DVT_ERR_UNSUPPORTED = the
+ *     program uses an instruction the prover has no chip for yet.
+ *   - buffers returned through `uint8_t **` are library-allocated, release with dvt_free().
+ *   - a dvt_prover is re-entrant per handle: one handle per caller thread (the
+ *     reference's HTTP node calls prove() from concurrent tokio workers,
+ *     src/service/node.rs:72-81), or serialise calls on a shared handle.
+ *   - "device field array": uint32_t words in HBM holding BabyBear elements in
+ *     the library's internal (Montgomery) representation, COLUMN-MAJOR
+ *     ([width][height], element (r,c) at c*height + r), natural row order.
+ */
+#ifndef DVT_PROVER_H
+#define DVT_PROVER_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVT_OK 0
+#define DVT_ERR_GUEST 1
+#define DVT_ERR_INPUT 2
+#define DVT_ERR_DEVICE 3
+#define DVT_ERR_UNSUPPORTED 4
+
+typedef struct dvt_prover dvt_prover;
+
+/* ---------------------------------------------------------------- lifecycle */
+/* ProverClient::from_env() (src/main.rs:438,461,481).  cfg_json may be NULL or
+ * a JSON object: {"device":0,"log_shard_size":21,"fri_queries":100,"pow_bits":16}. */
+int dvt_prover_create(const char *cfg_json, dvt_prover **out);
+void dvt_prover_destroy(dvt_prover *p);
+/* last error text of this handle (or of the failed create when p == NULL) */
+const char *dvt_last_error(const dvt_prover *p);
+void dvt_free(void *ptr);
+/* ABI version of this header */
+uint32_t dvt_abi_version(void);
+
+/* ------------------------------------------------- stage-level entry points
+ * One call = one kernel family of SURVEY.md section 8(a) on caller-owned device
+ * memory; used by the parity tests and by bench.py's roofline measurement.
+ * `stream` is a hipStream_t (NULL = the handle's own stream).  Asynchronous:
+ * call dvt_sync() before reading results on the host. */
+int dvt_sync(dvt_prover *p, void *stream);
+/* canonical <-> internal representation, in place, n words */
+int dvt_dev_to_internal(dvt_prover *p, void *stream, uint32_t *d_words, size_t n);
+int dvt_dev_from_internal(dvt_prover *p, void *stream, uint32_t *d_words, size_t n);
+
+/* K1: coset low-degree extension, blow-up 2.  d_in [width][2^log_n] holds
+ * evaluations over the subgroup H; d_out [width][2^(log_n+1)] receives the
+ * evaluations on shift*H', |H'| = 2|H|.  shift_mode: 0 = the generator 31 (trace
+ * commitments), 1 = 1, 2 = w_{2N}^-1 (the two quotient chunks).  d_in is used
+ * as scratch and is clobbered.  log_n <= 22. */
+int dvt_stage_coset_lde(dvt_prover *p, void *stream, uint32_t *d_in, uint32_t *d_out,
+                        uint32_t width, uint32_t log_n, uint32_t shift_mode);
+
+/* K2+K3: mixed-height Poseidon2 Merkle commitment. */
+typedef struct {
+    const uint32_t *d_data; /* device field array [width][2^log_height] */
+    uint32_t width;
+    uint32_t log_height;
+} dvt_dev_matrix;
+/* words the digest buffer must hold: (2*H - 1) * 8, H = tallest height */
+size_t dvt_merkle_digest_words(const dvt_dev_matrix *mats, size_t n);
+/* d_digests: layer 0 (H digests of 8 words) first, then H/2, ..., the root last */
+int dvt_stage_merkle_commit(dvt_prover *p, void *stream, const dvt_dev_matrix *mats, size_t n,
+                            uint32_t *d_digests);
+/* raw permutation on n states of 16 words each (device array [n][16]); test hook */
+int dvt_stage_poseidon2_permute(dvt_prover *p, void *stream, uint32_t *d_states, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,127 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see field.h).
+ *
+ * Poseidon2 over BabyBear, width 16, S-box x^7, 8 external (4+4) and 13
+ * internal rounds — the public parameter set the reference's dependency is
+ * believed to use (crate p3-poseidon2 / sp1-primitives,
+ * pinned only as sp1-sdk ^4.2.1 at reference Cargo.toml:31, source absent).
+ *   external layer: M4 = circ(2,3,1,1) on every 4-chunk, then add the column
+ *                   sums (Poseidon2 paper, section 5.1)
+ *   internal layer: y_i = diag_i * x_i + sum(x),  diag = [-2,1,2,4,...,2^13,2^15]
+ * The stock round-constant table (RC_16_30_U32, 480 words) is not in the
+ * container, so the constants are derived here:
+ *   block_i  = SHA-256("dvt-amd/poseidon2-babybear-w16/rc" || LE32(i))
+ *   4 constants per block = the four little-endian u64 words of block_i mod p
+ *   order: 8 rounds x 16 external constants, then 13 internal constants.
+ * The product path carries the same numbers as a generated table
+ * (tools/gen_poseidon2_rc.py); tests assert the two agree. */
+#include "dvt_oracle.h"
+#include "field.h"
+#include <string.h>
+
+#define N_EXT 8
+#define N_INT 13
+
+static bb_t RC_EXT[N_EXT][16];
+static bb_t RC_INT[N_INT];
+static bb_t DIAG[16];
+static int inited = 0;
+
+static void init_constants(void) {
+    if (inited) return;
+    static const char tag[] = "dvt-amd/poseidon2-babybear-w16/rc";
+    size_t tl = sizeof(tag) - 1;
+    uint8_t msg[64], dg[32];
+    memcpy(msg, tag, tl);
+    bb_t all[N_EXT * 16 + N_INT + 3];
+    size_t need = N_EXT * 16 + N_INT, have = 0;
+    for (uint32_t i = 0; have < need; i++) {
+        msg[tl] = (uint8_t)i; msg[tl + 1] = (uint8_t)(i >> 8); msg[tl + 2] = (uint8_t)(i >> 16); msg[tl + 3] = (uint8_t)(i >> 24);
+        orc_sha256(msg, tl + 4, dg);
+        for (int k = 0; k < 4; k++) {
+            uint64_t w = 0;
+            for (int b = 7; b >= 0; b--) w = (w << 8) | dg[8 * k + b];
+            all[have++] = (bb_t)(w % BB_P);
+        }
+    }
+    for (int r = 0; r < N_EXT; r++)
+        for (int j = 0; j < 16; j++) RC_EXT[r][j] = all[r * 16 + j];
+    for (int r = 0; r < N_INT; r++) RC_INT[r] = all[N_EXT * 16 + r];
+    DIAG[0] = BB_P - 2;
+    for (int i = 1; i < 15; i++) DIAG[i] = 1u << (i - 1);
+    DIAG[15] = 1u << 15;
+    inited = 1;
+}
+
+void orc_poseidon2_constants(uint32_t ext_rc[128], uint32_t int_rc[13], uint32_t diag[16]) {
+    init_constants();
+    memcpy(ext_rc, RC_EXT, sizeof RC_EXT);
+    memcpy(int_rc, RC_INT, sizeof RC_INT);
+    memcpy(diag, DIAG, sizeof DIAG);
+}
+
+static inline bb_t sbox(bb_t x) {
+    bb_t x2 = bb_mul(x, x), x3 = bb_mul(x2, x), x4 = bb_mul(x2, x2);
+    return bb_mul(x3, x4);
+}
+
+static void external_layer(bb_t s[16]) {
+    for (int c = 0; c < 4; c++) {
+        bb_t *x = s + 4 * c;
+        uint64_t x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
+        bb_t y0 = (bb_t)((2 * x0 + 3 * x1 + x2 + x3) % BB_P);
+        bb_t y1 = (bb_t)((x0 + 2 * x1 + 3 * x2 + x3) % BB_P);
+        bb_t y2 = (bb_t)((x0 + x1 + 2 * x2 + 3 * x3) % BB_P);
+        bb_t y3 = (bb_t)((3 * x0 + x1 + x2 + 2 * x3) % BB_P);
+        x[0] = y0; x[1] = y1; x[2] = y2; x[3] = y3;
+    }
+    for (int k = 0; k < 4; k++) {
+        bb_t sum = bb_add(bb_add(s[k], s[4 + k]), bb_add(s[8 + k], s[12 + k]));
+        for (int c = 0; c < 4; c++) s[4 * c + k] = bb_add(s[4 * c + k], sum);
+    }
+}
+
+static void internal_layer(bb_t s[16]) {
+    uint64_t sum = 0;
+    for (int i = 0; i < 16; i++) sum += s[i];
+    bb_t sm = (bb_t)(sum % BB_P);
+    for (int i = 0; i < 16; i++) s[i] = bb_add(bb_mul(s[i], DIAG[i]), sm);
+}
+
+void orc_poseidon2_permute(uint32_t s[16]) {
+    init_constants();
+    external_layer(s);
+    for (int r = 0; r < N_EXT / 2; r++) {
+        for (int i = 0; i < 16; i++) s[i] = sbox(bb_add(s[i], RC_EXT[r][i]));
+        external_layer(s);
+    }
+    for (int r = 0; r < N_INT; r++) {
+        s[0] = sbox(bb_add(s[0], RC_INT[r]));
+        internal_layer(s);
+    }
+    for (int r = N_EXT / 2; r < N_EXT; r++) {
+        for (int i = 0; i < 16; i++) s[i] = sbox(bb_add(s[i], RC_EXT[r][i]));
+        external_layer(s);
+    }
+}
+
+/* Padding-free sponge: overwrite the first `rate` lanes chunk by chunk, permute
+ * after every (possibly partial) chunk, squeeze lanes 0..7.  Empty input -> zeros. */
+void orc_hash_slice(const uint32_t *in, size_t n, uint32_t out[8]) {
+    uint32_t s[16];
+    memset(s, 0, sizeof s);
+    for (size_t i = 0; i < n; i += 8) {
+        size_t k = n - i < 8 ? n - i : 8;
+        memcpy(s, in + i, k * sizeof(uint32_t));
+        orc_poseidon2_permute(s);
+    }
+    memcpy(out, s, 8 * sizeof(uint32_t));
+}
+
+/* 2-to-1 truncated permutation */
+void orc_compress(const uint32_t l[8], const uint32_t r[8], uint32_t out[8]) {
+    uint32_t s[16];
+    memcpy(s, l, 32);
+    memcpy(s + 8, r, 32);
+    orc_poseidon2_permute(s);
+    memcpy(out, s, 32);
+}
