@@ -5,22 +5,30 @@ import ctypes as C
 import os
 import subprocess
 
+import numpy as np
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdvt_prover.so")
 CSRC = os.path.join(HERE, "csrc")
 
-DVT_OK, DVT_ERR_GUEST, DVT_ERR_INPUT, DVT_ERR_DEVICE, DVT_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
+DVT_OK, DVT_ERR_GUEST, DVT_ERR_INPUT, DVT_ERR_DEVICE, DVT_ERR_UNSUPPORTED, DVT_ERR_REJECTED = 0, 1, 2, 3, 4, 5
 u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
 
 
 class DevMatrix(C.Structure):
     _fields_ = [("d_data", C.c_void_p), ("width", C.c_uint32), ("log_height", C.c_uint32)]
 
 
+class HostTrace(C.Structure):
+    _fields_ = [("chip_id", C.c_uint32), ("log_n", C.c_uint32), ("data", u32p)]
+
+
 class DvtError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"dvt error {code}: {msg}")
         self.code = code
+        self.msg = msg
 
 
 def build():
@@ -47,16 +55,50 @@ def load():
     lib.dvt_last_error.restype = C.c_char_p
     lib.dvt_free.argtypes = [vp]
     lib.dvt_free.restype = None
-    lib.dvt_sync.argtypes = [vp, vp]
-    lib.dvt_dev_to_internal.argtypes = [vp, vp, vp, sz]
-    lib.dvt_dev_from_internal.argtypes = [vp, vp, vp, sz]
+    lib.dvt_stream.argtypes = [vp]
+    lib.dvt_stream.restype = vp
+    lib.dvt_sync.argtypes = [vp]
+    lib.dvt_dev_to_internal.argtypes = [vp, vp, sz]
+    lib.dvt_dev_from_internal.argtypes = [vp, vp, sz]
     lib.dvt_stage_coset_lde.argtypes = [vp, vp, vp, vp, u32, u32, u32]
     lib.dvt_merkle_digest_words.argtypes = [C.POINTER(DevMatrix), sz]
     lib.dvt_merkle_digest_words.restype = sz
-    lib.dvt_stage_merkle_commit.argtypes = [vp, vp, C.POINTER(DevMatrix), sz, vp]
-    lib.dvt_stage_poseidon2_permute.argtypes = [vp, vp, vp, sz]
+    lib.dvt_stage_merkle_commit.argtypes = [vp, C.POINTER(DevMatrix), sz, vp]
+    lib.dvt_stage_poseidon2_permute.argtypes = [vp, vp, sz]
+    lib.dvt_stage_fri_fold.argtypes = [vp, vp, vp, vp, u32p, u32]
+    lib.dvt_machine_setup.argtypes = [vp, C.c_char_p, C.POINTER(HostTrace), sz, C.POINTER(vp), C.POINTER(u8p), C.POINTER(sz)]
+    lib.dvt_pk_free.argtypes = [vp, vp]
+    lib.dvt_pk_free.restype = None
+    lib.dvt_machine_prove.argtypes = [vp, vp, C.POINTER(HostTrace), sz, u32p, sz, C.POINTER(u8p), C.POINTER(sz)]
+    lib.dvt_machine_verify.argtypes = [C.c_char_p, sz, C.c_char_p, sz, u32, u32, C.POINTER(C.c_char_p)]
+    lib.dvt_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
     _lib = lib
     return lib
+
+
+def _traces(traces):
+    """traces: list of (chip_id, ndarray [width][height] uint32 canonical)."""
+    arr = (HostTrace * max(len(traces), 1))()
+    keep = []
+    for i, (cid, m) in enumerate(traces):
+        m = np.ascontiguousarray(m, dtype=np.uint32)
+        h = m.shape[1]
+        lg = int(h).bit_length() - 1
+        assert 1 << lg == h
+        keep.append(m)
+        arr[i] = HostTrace(cid, lg, m.ctypes.data_as(u32p))
+    return arr, keep
+
+
+def machine_verify(vk: bytes, proof: bytes, fri_queries=100, pow_bits=16):
+    """Host-only verification.  Returns (ok, reason)."""
+    lib = load()
+    reason = C.c_char_p()
+    rc = lib.dvt_machine_verify(vk, len(vk), proof, len(proof), fri_queries, pow_bits, C.byref(reason))
+    why = reason.value.decode() if reason.value else ""
+    if reason.value:
+        lib.dvt_free(C.cast(reason, C.c_void_p))
+    return rc == DVT_OK, why
 
 
 class Prover:
@@ -85,21 +127,26 @@ class Prover:
         if rc:
             raise DvtError(rc, self.lib.dvt_last_error(self.h).decode())
 
-    def sync(self, stream=None):
-        self.check(self.lib.dvt_sync(self.h, stream))
+    def sync(self):
+        self.check(self.lib.dvt_sync(self.h))
+
+    def stream_ptr(self):
+        return self.lib.dvt_stream(self.h)
 
     # ---- stage-level helpers over torch int32 CUDA tensors (device memory plumbing only)
-    def to_internal(self, t, stream=None):
-        self.check(self.lib.dvt_dev_to_internal(self.h, stream, t.data_ptr(), t.numel()))
+    def to_internal(self, t):
+        self.check(self.lib.dvt_dev_to_internal(self.h, t.data_ptr(), t.numel()))
 
-    def from_internal(self, t, stream=None):
-        self.check(self.lib.dvt_dev_from_internal(self.h, stream, t.data_ptr(), t.numel()))
+    def from_internal(self, t):
+        self.check(self.lib.dvt_dev_from_internal(self.h, t.data_ptr(), t.numel()))
 
-    def coset_lde(self, t_in, t_out, width, log_n, shift_mode=0, stream=None):
+    def coset_lde(self, t_in, t_out, width, log_n, shift_mode=0, scratch=None):
         assert t_in.numel() == width << log_n and t_out.numel() == width << (log_n + 1)
-        self.check(self.lib.dvt_stage_coset_lde(self.h, stream, t_in.data_ptr(), t_out.data_ptr(), width, log_n, shift_mode))
+        assert scratch is None or scratch.numel() >= width << log_n
+        self.check(self.lib.dvt_stage_coset_lde(self.h, t_in.data_ptr(), scratch.data_ptr() if scratch is not None else None,
+                                                t_out.data_ptr(), width, log_n, shift_mode))
 
-    def merkle_commit(self, mats, t_digests, stream=None):
+    def merkle_commit(self, mats, t_digests):
         """mats: list of (tensor [width][height], width, log_height)."""
         arr = (DevMatrix * len(mats))()
         for i, (t, w, lh) in enumerate(mats):
@@ -107,9 +154,40 @@ class Prover:
             arr[i] = DevMatrix(t.data_ptr(), w, lh)
         need = self.lib.dvt_merkle_digest_words(arr, len(mats))
         assert t_digests.numel() >= need
-        self.check(self.lib.dvt_stage_merkle_commit(self.h, stream, arr, len(mats), t_digests.data_ptr()))
+        self.check(self.lib.dvt_stage_merkle_commit(self.h, arr, len(mats), t_digests.data_ptr()))
         return need
 
-    def poseidon2_permute(self, t_states, stream=None):
+    def poseidon2_permute(self, t_states):
         assert t_states.numel() % 16 == 0
-        self.check(self.lib.dvt_stage_poseidon2_permute(self.h, stream, t_states.data_ptr(), t_states.numel() // 16))
+        self.check(self.lib.dvt_stage_poseidon2_permute(self.h, t_states.data_ptr(), t_states.numel() // 16))
+
+    def fri_fold(self, t_v, t_out, beta, log_m, t_ro=None):
+        assert t_v.numel() == 4 << log_m and t_out.numel() == 2 << log_m
+        b = (C.c_uint32 * 4)(*[int(x) for x in beta])
+        self.check(self.lib.dvt_stage_fri_fold(self.h, t_v.data_ptr(), t_out.data_ptr(), t_ro.data_ptr() if t_ro is not None else None, b, log_m))
+
+    # ---- machine level
+    def machine_setup(self, machine: str, prep):
+        arr, keep = _traces(prep)
+        pk, vk, n = C.c_void_p(), u8p(), C.c_size_t()
+        self.check(self.lib.dvt_machine_setup(self.h, machine.encode(), arr, len(prep), C.byref(pk), C.byref(vk), C.byref(n)))
+        vkb = bytes(bytearray(vk[: n.value]))
+        self.lib.dvt_free(C.cast(vk, C.c_void_p))
+        return pk, vkb
+
+    def pk_free(self, pk):
+        self.lib.dvt_pk_free(self.h, pk)
+
+    def machine_prove(self, pk, main, pubs):
+        arr, keep = _traces(main)
+        pv = np.ascontiguousarray(pubs, dtype=np.uint32)
+        out, n = u8p(), C.c_size_t()
+        self.check(self.lib.dvt_machine_prove(self.h, pk, arr, len(main), pv.ctypes.data_as(u32p), pv.size, C.byref(out), C.byref(n)))
+        b = C.string_at(out, n.value)
+        self.lib.dvt_free(C.cast(out, C.c_void_p))
+        return b
+
+    def stage_ms(self):
+        out = (C.c_float * 6)()
+        self.check(self.lib.dvt_last_stage_ms(self.h, out))
+        return dict(zip(["commit_main", "permutation", "quotient", "openings", "fri", "total"], list(out)))

@@ -1,6 +1,6 @@
-// C-ABI layer (include/dvt_prover.h) over the gfx950 kernels.  There is no CPU
+// C-ABI layer (include/dvt_prover.h) over the gfx950 engine.  There is no CPU
 // fallback anywhere in this file: without a HIP device every entry point that
-// computes returns DVT_ERR_DEVICE.
+// computes returns DVT_ERR_DEVICE.  (dvt_machine_verify is host-only by nature.)
 #include "../../include/dvt_prover.h"
 
 #include <cstdarg>
@@ -10,25 +10,24 @@
 #include <mutex>
 #include <string>
 
-#include "kernels.h"
+#include "engine.h"
 
 using namespace dvt;
 
 struct dvt_prover {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    NttTables tabs;
-    // ring of device/pinned-host words for small per-launch tables (column pointer lists)
-    uint64_t *d_ring = nullptr, *h_ring = nullptr;
-    size_t ring_words = 0, ring_pos = 0;
+    Engine eng;
+    StarkConfig cfg;
     std::string err;
     std::mutex mu;
+};
+struct dvt_pk {
+    ProvingKey key;
 };
 
 static thread_local std::string g_create_err;
 
 static int fail(dvt_prover *p, int code, const char *fmt, ...) {
-    char buf[512];
+    char buf[600];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
@@ -36,9 +35,9 @@ static int fail(dvt_prover *p, int code, const char *fmt, ...) {
     if (p) p->err = buf; else g_create_err = buf;
     return code;
 }
-#define HIP_TRY(p, expr)                                                                       \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
+#define HIP_TRY(p, expr)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
         if (e_ != hipSuccess) return fail(p, DVT_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
@@ -52,9 +51,61 @@ static int cfg_int(const char *json, const char *key, int dflt) {
     return atoi(s + 1);
 }
 
+namespace dvt {
+const MachineDesc *machine_by_name(const char *name) {
+    if (!name) return nullptr;
+    if (!strcmp(name, "toy")) return machine_toy();
+    if (!strcmp(name, "rv32")) return machine_rv32();
+    return nullptr;
+}
+}  // namespace dvt
+
+static uint8_t *copy_out(const std::vector<uint32_t> &w, size_t *len) {
+    uint8_t *b = (uint8_t *)malloc(w.size() * 4 + 1);
+    if (!b) return nullptr;
+    memcpy(b, w.data(), w.size() * 4);
+    *len = w.size() * 4;
+    return b;
+}
+
+static std::vector<uint32_t> vk_words(const VerifyingKey &vk) {
+    WordWriter w;
+    w.u32(0x314b5644u);  // "DVK1"
+    char name[16] = {0};
+    strncpy(name, vk.machine->name, 15);
+    for (int i = 0; i < 4; i++) { uint32_t v; memcpy(&v, name + 4 * i, 4); w.u32(v); }
+    w.dg(vk.prep_root);
+    w.u32((uint32_t)vk.prep_chips.size());
+    for (auto &c : vk.prep_chips) { w.u32((uint32_t)c.chip_id); w.u32(c.log_n); }
+    return w.w;
+}
+static bool vk_parse(const uint8_t *b, size_t len, VerifyingKey *vk) {
+    if (len % 4 || len < 4 * 14) return false;
+    std::vector<uint32_t> wv(len / 4);
+    memcpy(wv.data(), b, len);
+    try {
+        WordReader r(wv.data(), wv.size());
+        if (r.u32() != 0x314b5644u) return false;
+        char name[17] = {0};
+        for (int i = 0; i < 4; i++) { uint32_t v = r.u32(); memcpy(name + 4 * i, &v, 4); }
+        vk->machine = machine_by_name(name);
+        if (!vk->machine) return false;
+        vk->prep_root = r.dg();
+        uint32_t n = r.len(64);
+        for (uint32_t i = 0; i < n; i++) {
+            ChipRef c;
+            c.chip_id = (int)r.u32();
+            c.log_n = r.u32();
+            if (c.chip_id < 0 || c.chip_id >= vk->machine->n_chips || c.log_n > 22) return false;
+            vk->prep_chips.push_back(c);
+        }
+    } catch (const std::exception &) { return false; }
+    return true;
+}
+
 extern "C" {
 
-uint32_t dvt_abi_version(void) { return 1; }
+uint32_t dvt_abi_version(void) { return 2; }
 
 int dvt_prover_create(const char *cfg_json, dvt_prover **out) {
     if (!out) return fail(nullptr, DVT_ERR_INPUT, "out == NULL");
@@ -72,12 +123,14 @@ int dvt_prover_create(const char *cfg_json, dvt_prover **out) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(nullptr, DVT_ERR_DEVICE, "device %d is %s; this library is built for gfx950 only", dev, prop.gcnArchName);
     dvt_prover *p = new dvt_prover();
-    p->device = dev;
-    e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = ntt_tables_create(&p->tabs);
-    p->ring_words = 1 << 17;
-    if (e == hipSuccess) e = hipMalloc(&p->d_ring, p->ring_words * 8);
-    if (e == hipSuccess) e = hipHostMalloc(&p->h_ring, p->ring_words * 8);
+    p->cfg.num_queries = (uint32_t)cfg_int(cfg_json, "fri_queries", 100);
+    p->cfg.pow_bits = (uint32_t)cfg_int(cfg_json, "pow_bits", 16);
+    p->eng.profile = cfg_int(cfg_json, "profile", 0) != 0;
+    if (p->cfg.num_queries == 0 || p->cfg.num_queries > 1024 || p->cfg.pow_bits > 30) {
+        delete p;
+        return fail(nullptr, DVT_ERR_INPUT, "fri_queries must be 1..1024 and pow_bits <= 30");
+    }
+    e = p->eng.init(dev);
     if (e != hipSuccess) {
         fail(nullptr, DVT_ERR_DEVICE, "handle setup: %s", hipGetErrorString(e));
         dvt_prover_destroy(p);
@@ -89,49 +142,42 @@ int dvt_prover_create(const char *cfg_json, dvt_prover **out) {
 
 void dvt_prover_destroy(dvt_prover *p) {
     if (!p) return;
-    (void)hipSetDevice(p->device);
-    if (p->stream) (void)hipStreamSynchronize(p->stream);
-    ntt_tables_destroy(&p->tabs);
-    if (p->d_ring) (void)hipFree(p->d_ring);
-    if (p->h_ring) (void)hipHostFree(p->h_ring);
-    if (p->stream) (void)hipStreamDestroy(p->stream);
+    p->eng.shutdown();
     delete p;
 }
 
 const char *dvt_last_error(const dvt_prover *p) { return p ? p->err.c_str() : g_create_err.c_str(); }
-
 void dvt_free(void *ptr) { free(ptr); }
+void *dvt_stream(dvt_prover *p) { return p ? (void *)p->eng.stream : nullptr; }
 
-static hipStream_t pick(dvt_prover *p, void *stream) { return stream ? (hipStream_t)stream : p->stream; }
-
-int dvt_sync(dvt_prover *p, void *stream) {
+int dvt_sync(dvt_prover *p) {
     if (!p) return DVT_ERR_INPUT;
-    HIP_TRY(p, hipSetDevice(p->device));
-    HIP_TRY(p, hipStreamSynchronize(pick(p, stream)));
+    HIP_TRY(p, hipSetDevice(p->eng.device));
+    HIP_TRY(p, hipStreamSynchronize(p->eng.stream));
     return DVT_OK;
 }
 
-int dvt_dev_to_internal(dvt_prover *p, void *stream, uint32_t *d, size_t n) {
+int dvt_dev_to_internal(dvt_prover *p, uint32_t *d, size_t n) {
     if (!p || (!d && n)) return fail(p, DVT_ERR_INPUT, "null argument");
-    HIP_TRY(p, hipSetDevice(p->device));
-    HIP_TRY(p, launch_to_internal(pick(p, stream), d, n));
+    HIP_TRY(p, hipSetDevice(p->eng.device));
+    HIP_TRY(p, launch_to_internal(p->eng.stream, d, n));
     return DVT_OK;
 }
-int dvt_dev_from_internal(dvt_prover *p, void *stream, uint32_t *d, size_t n) {
+int dvt_dev_from_internal(dvt_prover *p, uint32_t *d, size_t n) {
     if (!p || (!d && n)) return fail(p, DVT_ERR_INPUT, "null argument");
-    HIP_TRY(p, hipSetDevice(p->device));
-    HIP_TRY(p, launch_from_internal(pick(p, stream), d, n));
+    HIP_TRY(p, hipSetDevice(p->eng.device));
+    HIP_TRY(p, launch_from_internal(p->eng.stream, d, n));
     return DVT_OK;
 }
 
-int dvt_stage_coset_lde(dvt_prover *p, void *stream, uint32_t *d_in, uint32_t *d_out, uint32_t width, uint32_t log_n,
+int dvt_stage_coset_lde(dvt_prover *p, uint32_t *d_in, uint32_t *d_scratch, uint32_t *d_out, uint32_t width, uint32_t log_n,
                         uint32_t shift_mode) {
     if (!p) return DVT_ERR_INPUT;
     if (width && (!d_in || !d_out)) return fail(p, DVT_ERR_INPUT, "null matrix");
     if (log_n > 22) return fail(p, DVT_ERR_INPUT, "log_n %u > 22", log_n);
     if (shift_mode > 2) return fail(p, DVT_ERR_INPUT, "shift_mode %u", shift_mode);
-    HIP_TRY(p, hipSetDevice(p->device));
-    HIP_TRY(p, launch_coset_lde(pick(p, stream), p->tabs, d_in, d_out, width, log_n, shift_mode));
+    HIP_TRY(p, hipSetDevice(p->eng.device));
+    HIP_TRY(p, launch_coset_lde(p->eng.stream, p->eng.tabs, d_in, d_scratch, d_out, width, log_n, shift_mode));
     return DVT_OK;
 }
 
@@ -141,61 +187,160 @@ size_t dvt_merkle_digest_words(const dvt_dev_matrix *mats, size_t n) {
     return (((size_t)2 << mx) - 1) * 8;
 }
 
-// reserve `n` pointer slots in the ring, fill them on the host, queue the upload
-static int ring_upload(dvt_prover *p, hipStream_t st, const std::vector<uint64_t> &ptrs, const uint32_t *const **d_out) {
-    size_t n = ptrs.size();
-    if (n > p->ring_words) return fail(p, DVT_ERR_INPUT, "too many columns (%zu)", n);
-    if (p->ring_pos + n > p->ring_words) {
-        HIP_TRY(p, hipStreamSynchronize(st));
-        p->ring_pos = 0;
-    }
-    memcpy(p->h_ring + p->ring_pos, ptrs.data(), n * 8);
-    HIP_TRY(p, hipMemcpyAsync(p->d_ring + p->ring_pos, p->h_ring + p->ring_pos, n * 8, hipMemcpyHostToDevice, st));
-    *d_out = reinterpret_cast<const uint32_t *const *>(p->d_ring + p->ring_pos);
-    p->ring_pos += n;
-    return DVT_OK;
-}
-
-int dvt_stage_merkle_commit(dvt_prover *p, void *stream, const dvt_dev_matrix *mats, size_t n, uint32_t *d_digests) {
+int dvt_stage_merkle_commit(dvt_prover *p, const dvt_dev_matrix *mats, size_t n, uint32_t *d_digests) {
     if (!p) return DVT_ERR_INPUT;
     if (!mats || !n || !d_digests) return fail(p, DVT_ERR_INPUT, "null argument");
     std::lock_guard<std::mutex> lk(p->mu);
-    HIP_TRY(p, hipSetDevice(p->device));
-    hipStream_t st = pick(p, stream);
-    uint32_t mx = 0;
+    HIP_TRY(p, hipSetDevice(p->eng.device));
+    std::vector<Engine::DevMat> dm;
     for (size_t i = 0; i < n; i++) {
         if (mats[i].log_height > 30) return fail(p, DVT_ERR_INPUT, "log_height too large");
         if (mats[i].width && !mats[i].d_data) return fail(p, DVT_ERR_INPUT, "null matrix data");
-        mx = std::max(mx, mats[i].log_height);
+        dm.push_back({mats[i].d_data, mats[i].width, mats[i].log_height});
     }
-    uint32_t *prev = nullptr;
-    for (uint32_t lh = mx + 1; lh-- > 0;) {
-        std::vector<uint64_t> ptrs;
-        for (size_t i = 0; i < n; i++)
-            if (mats[i].log_height == lh)
-                for (uint32_t c = 0; c < mats[i].width; c++)
-                    ptrs.push_back((uint64_t)(uintptr_t)(mats[i].d_data + ((size_t)c << lh)));
-        const uint32_t *const *d_cols = nullptr;
-        if (!ptrs.empty()) {
-            int rc = ring_upload(p, st, ptrs, &d_cols);
-            if (rc) return rc;
-        }
-        if (lh == mx) {
-            HIP_TRY(p, launch_merkle_leaves(st, d_cols, (uint32_t)ptrs.size(), lh, d_digests));
-            prev = d_digests;
-        } else {
-            uint32_t *cur = prev + ((size_t)16 << lh);
-            HIP_TRY(p, launch_merkle_level(st, prev, d_cols, (uint32_t)ptrs.size(), lh, cur));
-            prev = cur;
-        }
-    }
+    if (!p->eng.commit_tree(dm, d_digests)) return fail(p, DVT_ERR_DEVICE, "%s", p->eng.err.c_str());
     return DVT_OK;
 }
 
-int dvt_stage_poseidon2_permute(dvt_prover *p, void *stream, uint32_t *d_states, size_t n) {
+int dvt_stage_poseidon2_permute(dvt_prover *p, uint32_t *d_states, size_t n) {
     if (!p || (!d_states && n)) return fail(p, DVT_ERR_INPUT, "null argument");
-    HIP_TRY(p, hipSetDevice(p->device));
-    HIP_TRY(p, launch_poseidon2_permute(pick(p, stream), d_states, n));
+    HIP_TRY(p, hipSetDevice(p->eng.device));
+    HIP_TRY(p, launch_poseidon2_permute(p->eng.stream, d_states, n));
+    return DVT_OK;
+}
+
+int dvt_stage_fri_fold(dvt_prover *p, const uint32_t *d_v, uint32_t *d_out, const uint32_t *d_ro, const uint32_t beta[4],
+                       uint32_t log_m) {
+    if (!p || !d_v || !d_out || !beta) return fail(p, DVT_ERR_INPUT, "null argument");
+    if (log_m < 1 || log_m > 23) return fail(p, DVT_ERR_INPUT, "log_m out of range");
+    Fp4 b;
+    for (int k = 0; k < 4; k++) {
+        if (beta[k] >= P) return fail(p, DVT_ERR_INPUT, "beta not canonical");
+        b.c[k] = Fp::from_canonical(beta[k]);
+    }
+    HIP_TRY(p, hipSetDevice(p->eng.device));
+    HIP_TRY(p, launch_fri_fold(p->eng.stream, p->eng.tabs, reinterpret_cast<const Fp4 *>(d_v), reinterpret_cast<Fp4 *>(d_out),
+                               reinterpret_cast<const Fp4 *>(d_ro), b, log_m));
+    return DVT_OK;
+}
+
+// ------------------------------------------------------------------ machine level
+int dvt_machine_setup(dvt_prover *p, const char *machine, const dvt_host_trace *prep, size_t nprep, dvt_pk **pk_out,
+                      uint8_t **vk, size_t *vk_len) {
+    if (!p || !pk_out) return fail(p, DVT_ERR_INPUT, "null argument");
+    std::lock_guard<std::mutex> lk(p->mu);
+    const MachineDesc *m = machine_by_name(machine);
+    if (!m) return fail(p, DVT_ERR_INPUT, "unknown machine '%s'", machine ? machine : "(null)");
+    std::vector<ChipRef> refs;
+    std::vector<std::vector<uint32_t>> host;
+    for (size_t i = 0; i < nprep; i++) {
+        if ((int)prep[i].chip_id >= m->n_chips || prep[i].log_n > 22 || !prep[i].data) return fail(p, DVT_ERR_INPUT, "bad preprocessed trace %zu", i);
+        if (i && prep[i].chip_id <= prep[i - 1].chip_id) return fail(p, DVT_ERR_INPUT, "preprocessed traces must be sorted by chip id");
+        size_t words = (size_t)m->chips[prep[i].chip_id].prep_w << prep[i].log_n;
+        for (size_t k = 0; k < words; k++)
+            if (prep[i].data[k] >= P) return fail(p, DVT_ERR_INPUT, "preprocessed trace %zu holds a non-canonical value", i);
+        refs.push_back({(int)prep[i].chip_id, prep[i].log_n});
+        host.emplace_back(prep[i].data, prep[i].data + words);
+    }
+    for (int c = 0; c < m->n_chips; c++)
+        if (m->chips[c].prep_w) {
+            bool have = false;
+            for (auto &r : refs) have |= r.chip_id == c;
+            if (!have) return fail(p, DVT_ERR_INPUT, "chip %s needs a preprocessed trace", m->chips[c].name);
+        }
+    dvt_pk *pk = new dvt_pk();
+    if (!p->eng.setup(m, refs, host, &pk->key)) {
+        p->eng.free_key(&pk->key);
+        delete pk;
+        return fail(p, DVT_ERR_DEVICE, "%s", p->eng.err.c_str());
+    }
+    if (vk && vk_len) {
+        *vk = copy_out(vk_words(pk->key.vk), vk_len);
+        if (!*vk) { p->eng.free_key(&pk->key); delete pk; return fail(p, DVT_ERR_DEVICE, "out of host memory"); }
+    }
+    *pk_out = pk;
+    return DVT_OK;
+}
+
+void dvt_pk_free(dvt_prover *p, dvt_pk *pk) {
+    if (!p || !pk) return;
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->eng.free_key(&pk->key);
+    delete pk;
+}
+
+int dvt_machine_prove(dvt_prover *p, const dvt_pk *pk, const dvt_host_trace *main, size_t nmain, const uint32_t *pubs, size_t npub,
+                      uint8_t **proof, size_t *proof_len) {
+    if (!p || !pk || !main || !nmain || !proof || !proof_len || (npub && !pubs)) return fail(p, DVT_ERR_INPUT, "null argument");
+    std::lock_guard<std::mutex> lk(p->mu);
+    const MachineDesc *m = pk->key.vk.machine;
+    HIP_TRY(p, hipSetDevice(p->eng.device));
+    std::vector<uint32_t *> dev(nmain, nullptr);
+    std::vector<ChipTrace> traces;
+    int rc = DVT_OK;
+    auto cleanup = [&] { for (auto d : dev) if (d) (void)hipFree(d); };
+    for (size_t i = 0; i < nmain && rc == DVT_OK; i++) {
+        if ((int)main[i].chip_id >= m->n_chips || main[i].log_n > 22 || !main[i].data) { rc = fail(p, DVT_ERR_INPUT, "bad main trace %zu", i); break; }
+        size_t words = (size_t)m->chips[main[i].chip_id].main_w << main[i].log_n;
+        for (size_t k = 0; k < words; k++)
+            if (main[i].data[k] >= P) { rc = fail(p, DVT_ERR_INPUT, "main trace %zu holds a non-canonical value", i); break; }
+        if (rc) break;
+        if (hipMalloc(&dev[i], words * 4) != hipSuccess || hipMemcpy(dev[i], main[i].data, words * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            launch_to_internal(p->eng.stream, dev[i], words) != hipSuccess) {
+            rc = fail(p, DVT_ERR_DEVICE, "uploading main trace %zu failed", i);
+            break;
+        }
+        traces.push_back({(int)main[i].chip_id, main[i].log_n, dev[i]});
+    }
+    if (rc) { cleanup(); return rc; }
+    std::vector<Fp> pv(npub);
+    for (size_t i = 0; i < npub; i++) {
+        if (pubs[i] >= P) { cleanup(); return fail(p, DVT_ERR_INPUT, "public value %zu not canonical", i); }
+        pv[i] = Fp::from_canonical(pubs[i]);
+    }
+    ShardProof sp;
+    bool ok = p->eng.prove_shard(pk->key, traces, pv, p->cfg, &sp);
+    (void)hipStreamSynchronize(p->eng.stream);
+    cleanup();
+    if (!ok) return fail(p, DVT_ERR_DEVICE, "%s", p->eng.err.c_str());
+    WordWriter w;
+    write_shard_proof(w, sp);
+    *proof = copy_out(w.w, proof_len);
+    if (!*proof) return fail(p, DVT_ERR_DEVICE, "out of host memory");
+    return DVT_OK;
+}
+
+int dvt_machine_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, size_t proof_len, uint32_t fri_queries,
+                       uint32_t pow_bits, char **reason) {
+    if (reason) *reason = nullptr;
+    auto reject = [&](int code, const std::string &why) {
+        if (reason) *reason = strdup(why.c_str());
+        return code;
+    };
+    if (!vk || !proof) return reject(DVT_ERR_INPUT, "null argument");
+    VerifyingKey key;
+    if (!vk_parse(vk, vk_len, &key)) return reject(DVT_ERR_INPUT, "malformed verifying key");
+    if (proof_len % 4) return reject(DVT_ERR_INPUT, "proof length is not a multiple of 4");
+    std::vector<uint32_t> words(proof_len / 4);
+    memcpy(words.data(), proof, proof_len);
+    ShardProof sp;
+    try {
+        WordReader r(words.data(), words.size());
+        sp = read_shard_proof(r);
+        if (r.p != r.end) return reject(DVT_ERR_REJECTED, "trailing bytes after proof");
+    } catch (const std::exception &e) { return reject(DVT_ERR_REJECTED, e.what()); }
+    StarkConfig cfg;
+    cfg.num_queries = fri_queries;
+    cfg.pow_bits = pow_bits;
+    std::string why = verify_shard(key, sp, cfg);
+    if (!why.empty()) return reject(DVT_ERR_REJECTED, why);
+    return DVT_OK;
+}
+
+int dvt_last_stage_ms(dvt_prover *p, float out[6]) {
+    if (!p || !out) return DVT_ERR_INPUT;
+    const StageTimes &t = p->eng.times;
+    out[0] = t.commit_main; out[1] = t.perm; out[2] = t.quotient; out[3] = t.open; out[4] = t.fri; out[5] = t.total;
     return DVT_OK;
 }
 

@@ -1,0 +1,117 @@
+// Shard prover / verifier for a generic multi-chip machine.  The prover keeps
+// every matrix in HBM (column-major, Montgomery form) for the whole shard and runs
+// K1-K9 on one HIP stream; the host only drives the transcript.
+//
+// Stands behind reference src/main.rs:462-466 (`setup`, `prove(..).run()`); the
+// protocol itself is an original restatement of the public multi-table STARK
+// structure, see DESIGN.md "Protocol".
+#pragma once
+#include <string>
+#include <vector>
+
+#include "challenger.h"
+#include "machine.h"
+#include "proof.h"
+
+namespace dvt {
+
+struct StarkConfig {
+    uint32_t num_queries = 100;
+    uint32_t pow_bits = 16;
+};
+
+struct ChipRef {
+    int chip_id;
+    uint32_t log_n;
+};
+
+struct VerifyingKey {
+    const MachineDesc *machine = nullptr;
+    Digest prep_root;                 // all-zero when the machine has no preprocessed chip
+    std::vector<ChipRef> prep_chips;  // chips with preprocessed columns (always part of every shard)
+};
+
+// FRI batching order of the LDE columns of log-height h: every column opened at two
+// points (preprocessed, main, permutation; tree-major, then chip, then column) first,
+// then the quotient columns (opened at zeta only).
+struct ColRef {
+    int tree, mat, col, chip_pos;
+};
+std::vector<ColRef> fri_columns(const MachineDesc *m, const std::vector<ChipRef> &chips, uint32_t h, uint32_t *n_two);
+void transcript_begin(Challenger &ch, const VerifyingKey &vk, const std::vector<ChipRef> &chips);
+
+// returns "" on success, otherwise the reason for rejection
+std::string verify_shard(const VerifyingKey &vk, const ShardProof &proof, const StarkConfig &cfg);
+
+#if defined(__HIPCC__)
+struct Arena {
+    char *base = nullptr;
+    size_t cap = 0, off = 0;
+    hipError_t reserve(size_t bytes);
+    void release();
+    void reset() { off = 0; }
+    template <class T> T *alloc(size_t n) {
+        size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+        if (off + bytes > cap) return nullptr;
+        T *p = reinterpret_cast<T *>(base + off);
+        off += bytes;
+        return p;
+    }
+};
+
+struct ChipTrace {
+    int chip_id;
+    uint32_t log_n;
+    const uint32_t *d_main;  // device [main_w][2^log_n], Montgomery form
+};
+
+struct ProvingKey {
+    VerifyingKey vk;
+    struct Prep { int chip_id; uint32_t log_n; uint32_t *d_trace, *d_lde; };
+    std::vector<Prep> prep;
+    uint32_t *d_prep_digests = nullptr;
+    uint32_t prep_log_h = 0;  // log2 of the tallest preprocessed LDE
+};
+
+struct StageTimes {  // milliseconds, HIP events on the prover stream
+    float commit_main = 0, perm = 0, quotient = 0, open = 0, fri = 0, total = 0;
+};
+
+class Engine {
+  public:
+    int device = 0;
+    hipStream_t stream = nullptr;
+    NttTables tabs;
+    std::string err;
+    StageTimes times;
+    bool profile = false;
+
+    hipError_t init(int dev);
+    void shutdown();
+    // small host->device tables (column pointer lists, powers, indices); stream-ordered
+    const void *upload(const void *host, size_t bytes);
+    template <class T> const T *upload_vec(const std::vector<T> &v) { return static_cast<const T *>(upload(v.data(), v.size() * sizeof(T))); }
+    bool download(void *host, const void *dev, size_t bytes);  // synchronises the stream
+
+    struct DevMat { const uint32_t *ptr; uint32_t width, log_h; };
+    bool commit_tree(const std::vector<DevMat> &mats, uint32_t *d_digests);
+    // upper levels of a tree whose 2^log_h leaf digests are already in place (no injection)
+    bool commit_tree_levels(uint32_t *d_digests, uint32_t log_h);
+
+    // host_prep[i]: canonical column-major trace of the i-th chip that has preprocessed columns
+    bool setup(const MachineDesc *m, const std::vector<ChipRef> &prep_chips, const std::vector<std::vector<uint32_t>> &host_prep,
+               ProvingKey *pk);
+    void free_key(ProvingKey *pk);
+    bool prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &traces, const std::vector<Fp> &pubs,
+                     const StarkConfig &cfg, ShardProof *out);
+
+    Arena arena;
+
+  private:
+    char *d_ring = nullptr, *h_ring = nullptr;
+    size_t ring_bytes = 0, ring_pos = 0;
+    bool fail(const char *fmt, ...);
+};
+#endif
+
+}  // namespace dvt

@@ -1,0 +1,644 @@
+// Shard prover orchestration (host side of K1-K9) — see engine.h.
+#include "engine.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+
+namespace dvt {
+
+// ------------------------------------------------------------------ shared layout helpers
+std::vector<ColRef> fri_columns(const MachineDesc *m, const std::vector<ChipRef> &chips, uint32_t h, uint32_t *n_two) {
+    std::vector<ColRef> out;
+    for (int tree = 0; tree < 3; tree++) {
+        int mat = 0;
+        for (size_t pos = 0; pos < chips.size(); pos++) {
+            const ChipDesc &d = m->chips[chips[pos].chip_id];
+            int w = tree == 0 ? d.prep_w : tree == 1 ? d.main_w : 4 * d.perm_ext_w;
+            if (w == 0) continue;
+            if (chips[pos].log_n + 1 == h)
+                for (int c = 0; c < w; c++) out.push_back({tree, mat, c, (int)pos});
+            mat++;
+        }
+    }
+    *n_two = (uint32_t)out.size();
+    for (size_t pos = 0; pos < chips.size(); pos++)
+        if (chips[pos].log_n + 1 == h)
+            for (int c = 0; c < 8; c++) out.push_back({3, (int)pos, c, (int)pos});
+    return out;
+}
+
+void transcript_begin(Challenger &ch, const VerifyingKey &vk, const std::vector<ChipRef> &chips) {
+    ch.observe(vk.prep_root);
+    ch.observe_u32((uint32_t)chips.size());
+    for (auto &c : chips) {
+        ch.observe_u32((uint32_t)c.chip_id);
+        ch.observe_u32(c.log_n);
+    }
+}
+
+// ------------------------------------------------------------------ arena / ring
+hipError_t Arena::reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    release();
+    hipError_t e = hipMalloc(&base, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+}
+void Arena::release() {
+    if (base) (void)hipFree(base);
+    base = nullptr;
+    cap = off = 0;
+}
+
+bool Engine::fail(const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+    return false;
+}
+#define HIPCHK(expr)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) return fail("%s: %s", #expr, hipGetErrorString(e_));     \
+    } while (0)
+
+hipError_t Engine::init(int dev) {
+    device = dev;
+    hipError_t e = hipSetDevice(dev);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = ntt_tables_create(&tabs);
+    ring_bytes = 16u << 20;
+    if (e == hipSuccess) e = hipMalloc(&d_ring, ring_bytes);
+    if (e == hipSuccess) e = hipHostMalloc(&h_ring, ring_bytes);
+    return e;
+}
+void Engine::shutdown() {
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    arena.release();
+    ntt_tables_destroy(&tabs);
+    if (d_ring) (void)hipFree(d_ring);
+    if (h_ring) (void)hipHostFree(h_ring);
+    if (stream) (void)hipStreamDestroy(stream);
+    d_ring = h_ring = nullptr;
+    stream = nullptr;
+}
+const void *Engine::upload(const void *host, size_t bytes) {
+    size_t need = (bytes + 255) & ~(size_t)255;
+    if (need > ring_bytes) { err = "upload larger than ring"; return nullptr; }
+    if (ring_pos + need > ring_bytes) {
+        if (hipStreamSynchronize(stream) != hipSuccess) { err = "ring sync failed"; return nullptr; }
+        ring_pos = 0;
+    }
+    memcpy(h_ring + ring_pos, host, bytes);
+    if (hipMemcpyAsync(d_ring + ring_pos, h_ring + ring_pos, bytes, hipMemcpyHostToDevice, stream) != hipSuccess) {
+        err = "ring upload failed";
+        return nullptr;
+    }
+    const void *r = d_ring + ring_pos;
+    ring_pos += need;
+    return r;
+}
+bool Engine::download(void *host, const void *dev, size_t bytes) {
+    HIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return true;
+}
+
+bool Engine::commit_tree(const std::vector<DevMat> &mats, uint32_t *d_digests) {
+    uint32_t mx = 0;
+    for (auto &m : mats) mx = std::max(mx, m.log_h);
+    uint32_t *prev = nullptr;
+    for (uint32_t lh = mx + 1; lh-- > 0;) {
+        std::vector<uint64_t> ptrs;
+        for (auto &m : mats)
+            if (m.log_h == lh)
+                for (uint32_t c = 0; c < m.width; c++) ptrs.push_back((uint64_t)(uintptr_t)(m.ptr + ((size_t)c << lh)));
+        const uint32_t *const *d_cols = nullptr;
+        if (!ptrs.empty()) {
+            d_cols = reinterpret_cast<const uint32_t *const *>(upload(ptrs.data(), ptrs.size() * 8));
+            if (!d_cols) return false;
+        }
+        if (lh == mx) {
+            HIPCHK(launch_merkle_leaves(stream, d_cols, (uint32_t)ptrs.size(), lh, d_digests));
+            prev = d_digests;
+        } else {
+            uint32_t *cur = prev + ((size_t)16 << lh);
+            HIPCHK(launch_merkle_level(stream, prev, d_cols, (uint32_t)ptrs.size(), lh, cur));
+            prev = cur;
+        }
+    }
+    return true;
+}
+
+bool Engine::commit_tree_levels(uint32_t *d_digests, uint32_t log_h) {
+    uint32_t *prev = d_digests;
+    for (uint32_t lh = log_h; lh-- > 0;) {
+        uint32_t *cur = prev + ((size_t)16 << lh);
+        HIPCHK(launch_merkle_level(stream, prev, nullptr, 0, lh, cur));
+        prev = cur;
+    }
+    return true;
+}
+
+static size_t tree_words(uint32_t log_h) { return (((size_t)2 << log_h) - 1) * 8; }
+static const uint32_t *tree_root(const uint32_t *d_digests, uint32_t log_h) { return d_digests + tree_words(log_h) - 8; }
+
+static Digest digest_from_words(const uint32_t w[8]) {
+    Digest d;
+    for (int i = 0; i < 8; i++) d.d[i] = Fp::raw(w[i]);
+    return d;
+}
+
+// ------------------------------------------------------------------ setup
+bool Engine::setup(const MachineDesc *m, const std::vector<ChipRef> &prep_chips,
+                   const std::vector<std::vector<uint32_t>> &host_prep, ProvingKey *pk) {
+    HIPCHK(hipSetDevice(device));
+    pk->vk.machine = m;
+    pk->vk.prep_chips = prep_chips;
+    for (int i = 0; i < 8; i++) pk->vk.prep_root.d[i] = Fp::zero();
+    if (prep_chips.empty()) return true;
+    if (prep_chips.size() != host_prep.size()) return fail("setup: %zu preprocessed chips but %zu traces", prep_chips.size(), host_prep.size());
+    std::vector<DevMat> mats;
+    uint32_t mx = 0;
+    size_t scratch_words = 0;
+    for (size_t i = 0; i < prep_chips.size(); i++) {
+        const ChipDesc &d = m->chips[prep_chips[i].chip_id];
+        size_t n = (size_t)1 << prep_chips[i].log_n;
+        if (d.prep_w == 0 || host_prep[i].size() != n * d.prep_w) return fail("setup: bad preprocessed trace for chip %s", d.name);
+        scratch_words = std::max(scratch_words, n * d.prep_w);
+    }
+    uint32_t *d_scratch = nullptr;
+    HIPCHK(hipMalloc(&d_scratch, scratch_words * 4));
+    for (size_t i = 0; i < prep_chips.size(); i++) {
+        const ChipDesc &d = m->chips[prep_chips[i].chip_id];
+        size_t n = (size_t)1 << prep_chips[i].log_n, words = n * d.prep_w;
+        ProvingKey::Prep pc{prep_chips[i].chip_id, prep_chips[i].log_n, nullptr, nullptr};
+        HIPCHK(hipMalloc(&pc.d_trace, words * 4));
+        HIPCHK(hipMalloc(&pc.d_lde, words * 8));
+        HIPCHK(hipMemcpyAsync(pc.d_trace, host_prep[i].data(), words * 4, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));  // host_prep[i] is pageable
+        HIPCHK(launch_to_internal(stream, pc.d_trace, words));
+        HIPCHK(launch_coset_lde(stream, tabs, pc.d_trace, d_scratch, pc.d_lde, d.prep_w, pc.log_n, 0));
+        pk->prep.push_back(pc);
+        mats.push_back({pc.d_lde, (uint32_t)d.prep_w, pc.log_n + 1});
+        mx = std::max(mx, pc.log_n + 1);
+    }
+    pk->prep_log_h = mx;
+    HIPCHK(hipMalloc(&pk->d_prep_digests, tree_words(mx) * 4));
+    if (!commit_tree(mats, pk->d_prep_digests)) return false;
+    uint32_t root[8];
+    if (!download(root, tree_root(pk->d_prep_digests, mx), 32)) return false;
+    pk->vk.prep_root = digest_from_words(root);
+    HIPCHK(hipFree(d_scratch));
+    return true;
+}
+
+void Engine::free_key(ProvingKey *pk) {
+    (void)hipSetDevice(device);
+    for (auto &p : pk->prep) {
+        if (p.d_trace) (void)hipFree(p.d_trace);
+        if (p.d_lde) (void)hipFree(p.d_lde);
+    }
+    pk->prep.clear();
+    if (pk->d_prep_digests) (void)hipFree(pk->d_prep_digests);
+    pk->d_prep_digests = nullptr;
+}
+
+// ------------------------------------------------------------------ prove
+namespace {
+struct ChipState {
+    const ChipDesc *d;
+    int id;
+    uint32_t log_n;
+    size_t n;
+    const uint32_t *main = nullptr, *prep = nullptr, *prep_lde = nullptr;
+    uint32_t *main_lde = nullptr, *perm = nullptr, *perm_lde = nullptr, *quot = nullptr, *quot_lde = nullptr;
+    Fp4 cumsum = Fp4::zero();
+};
+std::vector<Fp4> ext_powers(Fp4 base, size_t n, bool from_one) {
+    std::vector<Fp4> v(n);
+    Fp4 x = from_one ? Fp4::one() : base;
+    for (size_t i = 0; i < n; i++) { v[i] = x; x = x * base; }
+    return v;
+}
+struct EventTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t st;
+    bool on;
+    EventTimer(hipStream_t s, bool enable) : st(s), on(enable) {
+        if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
+    }
+    float stop() {
+        if (!on) return 0;
+        float ms = 0;
+        (void)hipEventRecord(b, st);
+        (void)hipEventSynchronize(b);
+        (void)hipEventElapsedTime(&ms, a, b);
+        (void)hipEventRecord(a, st);
+        return ms;
+    }
+    ~EventTimer() { if (on) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } }
+};
+}  // namespace
+
+bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &traces, const std::vector<Fp> &pubs,
+                         const StarkConfig &cfg, ShardProof *out) {
+    HIPCHK(hipSetDevice(device));
+    const MachineDesc *m = pk.vk.machine;
+    arena.reset();
+    times = StageTimes();
+    EventTimer tm(stream, profile), tm_total(stream, profile);
+
+    // ---- validate inputs and lay out per-chip state
+    std::vector<ChipState> cs;
+    std::vector<ChipRef> refs;
+    size_t max_mat_words = 0;
+    uint32_t max_log_n = 0;
+    size_t need = 0;
+    for (auto &t : traces) {
+        if (t.chip_id < 0 || t.chip_id >= m->n_chips) return fail("prove: chip id %d out of range", t.chip_id);
+        if (!cs.empty() && t.chip_id <= cs.back().id) return fail("prove: chip traces must be sorted by chip id");
+        if (t.log_n > 22) return fail("prove: log_n %u > 22", t.log_n);
+        ChipState s;
+        s.d = &m->chips[t.chip_id];
+        s.id = t.chip_id;
+        s.log_n = t.log_n;
+        s.n = (size_t)1 << t.log_n;
+        s.main = t.d_main;
+        if (s.d->main_w == 0 || !s.main) return fail("prove: chip %s has no main trace", s.d->name);
+        cs.push_back(s);
+        refs.push_back({t.chip_id, t.log_n});
+        max_log_n = std::max(max_log_n, t.log_n);
+        size_t w = std::max<size_t>({(size_t)s.d->main_w, (size_t)4 * s.d->perm_ext_w, 4});
+        max_mat_words = std::max(max_mat_words, w * s.n);
+        need += (size_t)(s.d->main_w * 2 + 4 * s.d->perm_ext_w * 3 + 8 * 3) * s.n * 4 + 16 * 256;
+    }
+    if (cs.empty()) return fail("prove: no chips");
+    for (auto &pc : pk.prep) {
+        bool found = false;
+        for (auto &s : cs)
+            if (s.id == pc.chip_id) {
+                if (s.log_n != pc.log_n) return fail("prove: chip %s height differs from its preprocessed trace", s.d->name);
+                s.prep = pc.d_trace;
+                s.prep_lde = pc.d_lde;
+                found = true;
+            }
+        if (!found) return fail("prove: preprocessed chip %d missing from the shard", pc.chip_id);
+    }
+    for (auto &s : cs)
+        if (s.d->prep_w && !s.prep) return fail("prove: chip %s needs a preprocessed trace (setup)", s.d->name);
+    const uint32_t hmax = max_log_n + 1;
+    // arena: traces/LDEs + trees + FRI vectors + opening scratch (generous bound)
+    need += max_mat_words * 4;
+    need += 3 * tree_words(hmax) * 4;
+    need += ((size_t)1 << hmax) * 16 * 4 + 2 * tree_words(hmax) * 4;
+    need += ((size_t)1 << max_log_n) * 16 * 3 + (64u << 20);
+    if (arena.cap < need) HIPCHK(arena.reserve(need + need / 8));
+#define ALLOC(var, T, count)                                                        \
+    do {                                                                            \
+        var = arena.alloc<T>(count);                                                \
+        if (!var) return fail("prove: device arena exhausted (%s)", #var);          \
+    } while (0)
+
+    uint32_t *d_scratch;
+    ALLOC(d_scratch, uint32_t, max_mat_words);
+    const uint32_t *d_pub = upload_vec(std::vector<uint32_t>([&] {
+        std::vector<uint32_t> w(std::max<size_t>(pubs.size(), 1), 0);
+        for (size_t i = 0; i < pubs.size(); i++) w[i] = pubs[i].v;
+        return w;
+    }()));
+    if (!d_pub) return false;
+
+    ShardProof &pf = *out;
+    pf = ShardProof();
+    pf.public_values = pubs;
+    Challenger ch;
+    transcript_begin(ch, pk.vk, refs);
+
+    // ---- 1. main trace: LDE + commit  (K1, K2, K3)
+    std::vector<DevMat> mats;
+    for (auto &s : cs) {
+        ALLOC(s.main_lde, uint32_t, (size_t)s.d->main_w * 2 * s.n);
+        HIPCHK(launch_coset_lde(stream, tabs, const_cast<uint32_t *>(s.main), d_scratch, s.main_lde, s.d->main_w, s.log_n, 0));
+        mats.push_back({s.main_lde, (uint32_t)s.d->main_w, s.log_n + 1});
+    }
+    uint32_t *d_main_tree;
+    ALLOC(d_main_tree, uint32_t, tree_words(hmax));
+    if (!commit_tree(mats, d_main_tree)) return false;
+    uint32_t rootw[8];
+    if (!download(rootw, tree_root(d_main_tree, hmax), 32)) return false;
+    pf.main_root = digest_from_words(rootw);
+    ch.observe(pf.main_root);
+    ch.observe_u32((uint32_t)pubs.size());
+    for (auto x : pubs) ch.observe(x);
+    times.commit_main = tm.stop();
+
+    // ---- 2. permutation trace (K4) + LDE + commit
+    Fp4 perm_alpha = ch.sample_ext(), beta = ch.sample_ext();
+    int max_arity = 1, max_folded = 1;
+    for (int i = 0; i < m->n_chips; i++) {
+        max_arity = std::max(max_arity, m->chips[i].max_arity);
+        max_folded = std::max(max_folded, m->chips[i].n_folded);
+    }
+    std::vector<Fp4> beta_pows = ext_powers(beta, max_arity, false);
+    const Fp4 *d_beta = upload_vec(beta_pows);
+    if (!d_beta) return false;
+    mats.clear();
+    uint32_t perm_hmax = 0;
+    for (auto &s : cs) {
+        if (!s.d->perm_ext_w) continue;
+        const size_t bw = 4 * (size_t)s.d->perm_ext_w;
+        ALLOC(s.perm, uint32_t, bw * s.n);
+        ALLOC(s.perm_lde, uint32_t, bw * 2 * s.n);
+        PermArgs pa{s.main, s.prep, d_pub, s.perm, d_beta, perm_alpha, s.log_n};
+        HIPCHK(s.d->launch_perm(stream, pa));
+        uint32_t *phi = s.perm + (bw - 4) * s.n;
+        uint32_t *scan_scratch;
+        ALLOC(scan_scratch, uint32_t, prefix_sum_scratch_words(4, s.n));
+        HIPCHK(launch_prefix_sum_columns(stream, phi, 4, s.n, scan_scratch));
+        uint32_t cw[4];
+        for (int k = 0; k < 4; k++)
+            HIPCHK(hipMemcpyAsync(&cw[k], phi + (size_t)k * s.n + s.n - 1, 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        for (int k = 0; k < 4; k++) s.cumsum.c[k] = Fp::raw(cw[k]);
+        HIPCHK(launch_coset_lde(stream, tabs, s.perm, d_scratch, s.perm_lde, (uint32_t)bw, s.log_n, 0));
+        mats.push_back({s.perm_lde, (uint32_t)bw, s.log_n + 1});
+        perm_hmax = std::max(perm_hmax, s.log_n + 1);
+    }
+    uint32_t *d_perm_tree = nullptr;
+    for (int i = 0; i < 8; i++) pf.perm_root.d[i] = Fp::zero();
+    if (!mats.empty()) {
+        ALLOC(d_perm_tree, uint32_t, tree_words(perm_hmax));
+        if (!commit_tree(mats, d_perm_tree)) return false;
+        if (!download(rootw, tree_root(d_perm_tree, perm_hmax), 32)) return false;
+        pf.perm_root = digest_from_words(rootw);
+    }
+    ch.observe(pf.perm_root);
+    for (auto &s : cs) ch.observe(s.cumsum);
+    times.perm = tm.stop();
+
+    // ---- 3. quotient (K5) + chunk LDE + commit
+    Fp4 alpha = ch.sample_ext();
+    std::vector<Fp4> alpha_pows = ext_powers(alpha, max_folded, true);
+    const Fp4 *d_alpha = upload_vec(alpha_pows);
+    if (!d_alpha) return false;
+    mats.clear();
+    const Fp g = Fp::from_canonical(COSET_SHIFT);
+    for (auto &s : cs) {
+        ALLOC(s.quot, uint32_t, 8 * s.n);
+        ALLOC(s.quot_lde, uint32_t, 16 * s.n);
+        QuotientArgs qa;
+        qa.main_lde = s.main_lde; qa.prep_lde = s.prep_lde; qa.perm_lde = s.perm_lde; qa.pub = d_pub; qa.out = s.quot;
+        qa.alpha_pows = d_alpha; qa.beta_pows = d_beta; qa.perm_alpha = perm_alpha; qa.cumsum = s.cumsum;
+        Fp gn = pow(g, s.n);
+        qa.z_even = gn - Fp::one();
+        qa.z_odd = -gn - Fp::one();
+        qa.zinv_even = inv(qa.z_even);
+        qa.zinv_odd = inv(qa.z_odd);
+        qa.w_inv = inv(two_adic_generator(s.log_n));
+        qa.log_n = s.log_n;
+        qa.tabs = tabs;
+        HIPCHK(s.d->launch_quotient(stream, qa));
+        HIPCHK(launch_coset_lde(stream, tabs, s.quot, d_scratch, s.quot_lde, 4, s.log_n, 1));
+        HIPCHK(launch_coset_lde(stream, tabs, s.quot + 4 * s.n, d_scratch, s.quot_lde + 8 * s.n, 4, s.log_n, 2));
+        mats.push_back({s.quot_lde, 8, s.log_n + 1});
+    }
+    uint32_t *d_quot_tree;
+    ALLOC(d_quot_tree, uint32_t, tree_words(hmax));
+    if (!commit_tree(mats, d_quot_tree)) return false;
+    if (!download(rootw, tree_root(d_quot_tree, hmax), 32)) return false;
+    pf.quot_root = digest_from_words(rootw);
+    ch.observe(pf.quot_root);
+    times.quotient = tm.stop();
+
+    // ---- 4. openings at zeta and zeta*omega (K6)
+    Fp4 zeta = ch.sample_ext();
+    {
+        Fp4 *d_w;
+        ALLOC(d_w, Fp4, (size_t)1 << max_log_n);
+        size_t max_cols = 8;
+        for (auto &s : cs) max_cols = std::max<size_t>({max_cols, (size_t)s.d->main_w, (size_t)4 * s.d->perm_ext_w, (size_t)s.d->prep_w});
+        Fp4 *d_partial, *d_res;
+        ALLOC(d_partial, Fp4, (size_t)64 * max_cols * 2);
+        ALLOC(d_res, Fp4, max_cols * 2);
+        std::vector<Fp4> host_res(max_cols * 2);
+        std::map<uint32_t, bool> weights_ready;
+        auto open_matrix = [&](const uint32_t *base, uint32_t width, const ChipState &s, Fp4 scale, std::vector<Fp4> *local,
+                               std::vector<Fp4> *next) -> bool {
+            std::vector<uint64_t> ptrs(width);
+            for (uint32_t c = 0; c < width; c++) ptrs[c] = (uint64_t)(uintptr_t)(base + (size_t)c * s.n);
+            auto d_cols = reinterpret_cast<const uint32_t *const *>(upload(ptrs.data(), width * 8));
+            if (!d_cols) return false;
+            HIPCHK(launch_open_columns(stream, d_cols, width, s.log_n, d_w, d_partial, d_res));
+            if (!download(host_res.data(), d_res, (size_t)width * 2 * sizeof(Fp4))) return false;
+            local->resize(width);
+            if (next) next->resize(width);
+            for (uint32_t c = 0; c < width; c++) {
+                (*local)[c] = host_res[2 * c] * scale;
+                if (next) (*next)[c] = host_res[2 * c + 1] * scale;
+            }
+            return true;
+        };
+        pf.chips.resize(cs.size());
+        for (size_t k = 0; k < cs.size(); k++) {
+            ChipState &s = cs[k];
+            ChipOpening &o = pf.chips[k];
+            o.chip_id = (uint32_t)s.id;
+            o.log_n = s.log_n;
+            o.cumsum = s.cumsum;
+            Fp ninv = inv(Fp::from_canonical((uint32_t)(s.n % P)));
+            // trace matrices: point zeta over H
+            HIPCHK(launch_open_weights(stream, tabs, zeta, s.log_n, d_w));
+            Fp4 scale = (pow(zeta, s.n) - Fp::one()) * ninv;
+            if (s.d->prep_w && !open_matrix(s.prep, s.d->prep_w, s, scale, &o.prep_l, &o.prep_n)) return false;
+            if (!open_matrix(s.main, s.d->main_w, s, scale, &o.main_l, &o.main_n)) return false;
+            if (s.d->perm_ext_w && !open_matrix(s.perm, 4 * s.d->perm_ext_w, s, scale, &o.perm_l, &o.perm_n)) return false;
+            // quotient chunks: values on s_c * H, opened at zeta  <=>  f(y) = r(s_c y) at y = zeta / s_c
+            o.quot.resize(8);
+            for (int c = 0; c < 2; c++) {
+                Fp sc = c == 0 ? g : g * two_adic_generator(s.log_n + 1);
+                Fp4 y = zeta * inv(sc);
+                HIPCHK(launch_open_weights(stream, tabs, y, s.log_n, d_w));
+                Fp4 qs = (pow(y, s.n) - Fp::one()) * ninv;
+                std::vector<Fp4> vals;
+                if (!open_matrix(s.quot + (size_t)4 * c * s.n, 4, s, qs, &vals, nullptr)) return false;
+                for (int j = 0; j < 4; j++) o.quot[4 * c + j] = vals[j];
+            }
+        }
+        for (auto &o : pf.chips) {
+            for (auto *v : {&o.prep_l, &o.prep_n, &o.main_l, &o.main_n, &o.perm_l, &o.perm_n, &o.quot})
+                for (auto &x : *v) ch.observe(x);
+        }
+    }
+    times.open = tm.stop();
+
+    // ---- 5. FRI input (K7)
+    Fp4 alpha_fri = ch.sample_ext();
+    std::vector<Fp4 *> ro(hmax + 1, nullptr);
+    // matrices per tree in tree order, for pointer tables
+    struct TreeMat { const uint32_t *lde; uint32_t width, log_h; };
+    std::vector<TreeMat> tree_mats[4];
+    for (auto &s : cs) {
+        if (s.d->prep_w) tree_mats[0].push_back({s.prep_lde, (uint32_t)s.d->prep_w, s.log_n + 1});
+        tree_mats[1].push_back({s.main_lde, (uint32_t)s.d->main_w, s.log_n + 1});
+        if (s.d->perm_ext_w) tree_mats[2].push_back({s.perm_lde, (uint32_t)(4 * s.d->perm_ext_w), s.log_n + 1});
+        tree_mats[3].push_back({s.quot_lde, 8, s.log_n + 1});
+    }
+    {
+        size_t max_cols_h = 1;
+        std::vector<std::vector<ColRef>> cols_by_h(hmax + 1);
+        std::vector<uint32_t> n_two_by_h(hmax + 1, 0);
+        for (uint32_t h = 1; h <= hmax; h++) {
+            cols_by_h[h] = fri_columns(m, refs, h, &n_two_by_h[h]);
+            max_cols_h = std::max(max_cols_h, cols_by_h[h].size());
+        }
+        std::vector<Fp4> apow = ext_powers(alpha_fri, max_cols_h + 1, true);
+        const Fp4 *d_apow = upload_vec(apow);
+        if (!d_apow) return false;
+        for (uint32_t h = 1; h <= hmax; h++) {
+            auto &cols = cols_by_h[h];
+            if (cols.empty()) continue;
+            std::vector<uint64_t> ptrs(cols.size());
+            Fp4 sz_all = Fp4::zero(), sz_two = Fp4::zero();
+            for (size_t c = 0; c < cols.size(); c++) {
+                const ColRef &r = cols[c];
+                const TreeMat &tmx = tree_mats[r.tree][r.mat];
+                ptrs[c] = (uint64_t)(uintptr_t)(tmx.lde + ((size_t)r.col << h));
+                const ChipOpening &o = pf.chips[r.chip_pos];
+                const std::vector<Fp4> &loc = r.tree == 0 ? o.prep_l : r.tree == 1 ? o.main_l : r.tree == 2 ? o.perm_l : o.quot;
+                sz_all += apow[c] * loc[r.col];
+                if (r.tree < 3) {
+                    const std::vector<Fp4> &nx = r.tree == 0 ? o.prep_n : r.tree == 1 ? o.main_n : o.perm_n;
+                    sz_two += apow[c] * nx[r.col];
+                }
+            }
+            auto d_cols = reinterpret_cast<const uint32_t *const *>(upload(ptrs.data(), ptrs.size() * 8));
+            if (!d_cols) return false;
+            ALLOC(ro[h], Fp4, (size_t)1 << h);
+            Fp4 zeta_next = zeta * two_adic_generator(h - 1);
+            HIPCHK(launch_reduced_opening(stream, tabs, d_cols, n_two_by_h[h], (uint32_t)cols.size(), h, d_apow, sz_all, sz_two,
+                                          zeta, zeta_next, apow[cols.size()], ro[h]));
+        }
+    }
+
+    // ---- 6. FRI commit phase (K8)
+    struct Layer { Fp4 *v; uint32_t *tree; uint32_t log_m; };
+    std::vector<Layer> layers;
+    Fp4 *cur = ro[hmax];
+    for (uint32_t lm = hmax; lm > 1; lm--) {
+        Layer L{cur, nullptr, lm};
+        ALLOC(L.tree, uint32_t, tree_words(lm - 1));
+        HIPCHK(launch_fri_leaves(stream, cur, lm, L.tree));
+        if (!commit_tree_levels(L.tree, lm - 1)) return false;
+        if (!download(rootw, tree_root(L.tree, lm - 1), 32)) return false;
+        Digest root = digest_from_words(rootw);
+        pf.fri_roots.push_back(root);
+        ch.observe(root);
+        Fp4 fold_beta = ch.sample_ext();
+        Fp4 *nxt;
+        ALLOC(nxt, Fp4, (size_t)1 << (lm - 1));
+        HIPCHK(launch_fri_fold(stream, tabs, cur, nxt, ro[lm - 1], fold_beta, lm));
+        layers.push_back(L);
+        cur = nxt;
+    }
+    {
+        uint32_t fw[8];
+        if (!download(fw, cur, 32)) return false;  // two values, both equal to the constant final polynomial
+        for (int k = 0; k < 4; k++) pf.final_poly.c[k] = Fp::raw(fw[k]);
+        for (int k = 0; k < 4; k++)
+            if (fw[k] != fw[4 + k]) return fail("prove: FRI final polynomial is not constant (trace does not satisfy the AIR?)");
+        ch.observe(pf.final_poly);
+    }
+
+    // ---- 7. proof of work + queries (K9)
+    {
+        uint32_t st16[16];
+        for (int k = 0; k < 16; k++) st16[k] = ch.state[k].v;
+        for (size_t k = 0; k < ch.input.size(); k++) st16[k] = ch.input[k].v;
+        uint32_t pos = (uint32_t)ch.input.size();
+        uint32_t *d_found;
+        ALLOC(d_found, uint32_t, 1);
+        uint32_t found = 0xffffffffu;
+        for (uint32_t base = 0; found == 0xffffffffu && base < P - (1u << 22); base += 1u << 22) {
+            HIPCHK(hipMemsetAsync(d_found, 0xff, 4, stream));
+            HIPCHK(launch_pow_grind(stream, st16, pos, cfg.pow_bits, base, 1u << 22, d_found));
+            if (!download(&found, d_found, 4)) return false;
+        }
+        if (found == 0xffffffffu) return fail("prove: no proof-of-work witness found");
+        pf.pow_witness = Fp::from_canonical(found);
+        if (!ch.check_witness(cfg.pow_bits, pf.pow_witness)) return fail("prove: internal error, grind witness rejected by transcript");
+    }
+    const uint32_t nq = cfg.num_queries;
+    std::vector<uint32_t> idx(nq);
+    for (auto &i : idx) i = ch.sample_bits(hmax);
+    const uint32_t *d_idx = upload_vec(idx);
+    if (!d_idx) return false;
+    pf.queries.assign(nq, QueryProof());
+    const uint32_t *trees_dev[4] = {pk.d_prep_digests, d_main_tree, d_perm_tree, d_quot_tree};
+    const uint32_t trees_h[4] = {pk.prep_log_h, hmax, perm_hmax, hmax};
+    for (int t = 0; t < 4; t++) {
+        if (tree_mats[t].empty()) continue;
+        std::vector<uint64_t> ptrs;
+        std::vector<uint32_t> lhs;
+        for (auto &tmx : tree_mats[t])
+            for (uint32_t c = 0; c < tmx.width; c++) {
+                ptrs.push_back((uint64_t)(uintptr_t)(tmx.lde + ((size_t)c << tmx.log_h)));
+                lhs.push_back(tmx.log_h);
+            }
+        auto d_cols = reinterpret_cast<const uint32_t *const *>(upload(ptrs.data(), ptrs.size() * 8));
+        const uint32_t *d_lh = upload_vec(lhs);
+        if (!d_cols || !d_lh) return false;
+        uint32_t ncols = (uint32_t)ptrs.size();
+        uint32_t *d_rows, *d_paths;
+        ALLOC(d_rows, uint32_t, (size_t)nq * ncols);
+        ALLOC(d_paths, uint32_t, (size_t)nq * trees_h[t] * 8 + 8);
+        HIPCHK(launch_gather_rows(stream, d_cols, d_lh, ncols, d_idx, nq, d_rows));
+        HIPCHK(launch_gather_paths(stream, trees_dev[t], trees_h[t], d_idx, nq, d_paths));
+        std::vector<uint32_t> rows((size_t)nq * ncols), paths((size_t)nq * trees_h[t] * 8);
+        if (!download(rows.data(), d_rows, rows.size() * 4)) return false;
+        if (!paths.empty() && !download(paths.data(), d_paths, paths.size() * 4)) return false;
+        for (uint32_t q = 0; q < nq; q++) {
+            TreeOpening &to = pf.queries[q].trees[t];
+            size_t at = (size_t)q * ncols;
+            for (auto &tmx : tree_mats[t]) {
+                std::vector<Fp> row(tmx.width);
+                for (uint32_t c = 0; c < tmx.width; c++) row[c] = Fp::raw(rows[at + c]);
+                at += tmx.width;
+                to.rows.push_back(std::move(row));
+            }
+            to.path.resize(trees_h[t]);
+            for (uint32_t l = 0; l < trees_h[t]; l++) to.path[l] = digest_from_words(&paths[((size_t)q * trees_h[t] + l) * 8]);
+        }
+    }
+    for (auto &L : layers) {
+        Fp4 *d_sib;
+        uint32_t *d_paths;
+        const uint32_t th = L.log_m - 1;
+        ALLOC(d_sib, Fp4, nq);
+        ALLOC(d_paths, uint32_t, (size_t)nq * th * 8 + 8);
+        HIPCHK(launch_gather_siblings(stream, L.v, L.log_m, d_idx, nq, d_sib));
+        HIPCHK(launch_gather_paths(stream, L.tree, th, d_idx, nq, d_paths));
+        std::vector<uint32_t> sib((size_t)nq * 4), paths((size_t)nq * th * 8);
+        if (!download(sib.data(), d_sib, sib.size() * 4)) return false;
+        if (!paths.empty() && !download(paths.data(), d_paths, paths.size() * 4)) return false;
+        for (uint32_t q = 0; q < nq; q++) {
+            FriLayerOpening lo;
+            for (int k = 0; k < 4; k++) lo.sibling.c[k] = Fp::raw(sib[(size_t)q * 4 + k]);
+            lo.path.resize(th);
+            for (uint32_t l = 0; l < th; l++) lo.path[l] = digest_from_words(&paths[((size_t)q * th + l) * 8]);
+            pf.queries[q].layers.push_back(std::move(lo));
+        }
+    }
+    times.fri = tm.stop();
+    times.total = tm_total.stop();
+    return true;
+#undef ALLOC
+}
+
+}  // namespace dvt

@@ -24,8 +24,8 @@ hipError_t ntt_tables_create(NttTables *t);
 void ntt_tables_destroy(NttTables *t);
 
 // ntt.hip
-hipError_t launch_coset_lde(hipStream_t st, const NttTables &tabs, uint32_t *d_in, uint32_t *d_out, uint32_t width,
-                            uint32_t log_n, uint32_t shift_mode);
+hipError_t launch_coset_lde(hipStream_t st, const NttTables &tabs, uint32_t *d_in, uint32_t *d_scratch, uint32_t *d_out,
+                            uint32_t width, uint32_t log_n, uint32_t shift_mode);
 hipError_t launch_to_internal(hipStream_t st, uint32_t *d, size_t n);
 hipError_t launch_from_internal(hipStream_t st, uint32_t *d, size_t n);
 
@@ -33,10 +33,31 @@ hipError_t launch_from_internal(hipStream_t st, uint32_t *d, size_t n);
 // d_cols: device array of `ncols` column base pointers (each column has `height` words)
 hipError_t launch_merkle_leaves(hipStream_t st, const uint32_t *const *d_cols, uint32_t ncols, uint32_t log_height,
                                 uint32_t *d_out);
-// d_out[i] = compress(prev[2i], prev[2i+1]); with ncols > 0 additionally
+// d_out[i] = compress(prev[i], prev[i + len]); with ncols > 0 additionally
 // d_out[i] = compress(d_out[i], sponge(row i of the injected columns))
 hipError_t launch_merkle_level(hipStream_t st, const uint32_t *d_prev, const uint32_t *const *d_cols, uint32_t ncols,
                                uint32_t log_len, uint32_t *d_out);
 hipError_t launch_poseidon2_permute(hipStream_t st, uint32_t *d_states, size_t n);
+
+// fri.hip
+hipError_t launch_prefix_sum_columns(hipStream_t st, uint32_t *d_cols, uint32_t ncols, size_t n, uint32_t *d_scratch);
+size_t prefix_sum_scratch_words(uint32_t ncols, size_t n);
+hipError_t launch_open_weights(hipStream_t st, const NttTables &tabs, Fp4 z, uint32_t log_n, Fp4 *d_w);
+uint32_t open_row_blocks(uint32_t log_n);
+hipError_t launch_open_columns(hipStream_t st, const uint32_t *const *d_cols, uint32_t ncols, uint32_t log_n, const Fp4 *d_w,
+                               Fp4 *d_partial, Fp4 *d_out);
+hipError_t launch_reduced_opening(hipStream_t st, const NttTables &tabs, const uint32_t *const *d_cols, uint32_t n_two,
+                                  uint32_t n_all, uint32_t log_m, const Fp4 *d_alpha_pows, Fp4 sz_all, Fp4 sz_two, Fp4 zeta,
+                                  Fp4 zeta_next, Fp4 alpha_shift, Fp4 *d_out);
+hipError_t launch_fri_fold(hipStream_t st, const NttTables &tabs, const Fp4 *d_v, Fp4 *d_out, const Fp4 *d_ro, Fp4 beta,
+                           uint32_t log_m);
+hipError_t launch_fri_leaves(hipStream_t st, const Fp4 *d_v, uint32_t log_m, uint32_t *d_digests);
+hipError_t launch_gather_rows(hipStream_t st, const uint32_t *const *d_cols, const uint32_t *d_log_h, uint32_t ncols,
+                              const uint32_t *d_idx, uint32_t nq, uint32_t *d_out);
+hipError_t launch_gather_paths(hipStream_t st, const uint32_t *d_digests, uint32_t log_h, const uint32_t *d_idx, uint32_t nq,
+                               uint32_t *d_out);
+hipError_t launch_gather_siblings(hipStream_t st, const Fp4 *d_v, uint32_t log_m, const uint32_t *d_idx, uint32_t nq, Fp4 *d_out);
+hipError_t launch_pow_grind(hipStream_t st, const uint32_t state[16], uint32_t pos, uint32_t bits, uint32_t base, uint32_t count,
+                            uint32_t *d_found);
 
 }  // namespace dvt

@@ -7,8 +7,10 @@
 // column: every global load is a fully coalesced 256-B request, and the column
 // base pointers come from a wave-uniform (scalar) pointer table, which lets one
 // kernel hash the concatenation of any number of equal-height matrices.
-// Digests are stored array-of-structs ([node][8] words, 32 B) so a parent reads
-// its two children as one contiguous 64-B run.
+// Digests are stored array-of-structs ([node][8] words, 32 B).  Pairing is
+// natural-order: parent i of a layer of L nodes = compress(child i, child i+L),
+// so row r of a tall matrix and row r mod L of a shorter one share a path (the
+// relation natural-order FRI folding needs) and both child reads are coalesced.
 //
 // ALU-bound (about 141 S-boxes = 564 Montgomery products per permutation, one
 // permutation per 8 input words), not HBM-bound: see DESIGN.md.
@@ -53,8 +55,10 @@ __global__ void __launch_bounds__(256) merkle_level_kernel(const uint32_t *prev,
                                                           uint32_t ncols, size_t len, uint32_t *out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= len) return;
-    const uint4 *p = reinterpret_cast<const uint4 *>(prev + i * 16);
-    uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+    // natural-order pairing: children i and i + len (two coalesced 32-B-per-lane streams)
+    const uint4 *pl = reinterpret_cast<const uint4 *>(prev + i * 8);
+    const uint4 *pr = reinterpret_cast<const uint4 *>(prev + (i + len) * 8);
+    uint4 a = pl[0], b = pl[1], c = pr[0], d = pr[1];
     Fp s[16] = {Fp::raw(a.x), Fp::raw(a.y), Fp::raw(a.z), Fp::raw(a.w), Fp::raw(b.x), Fp::raw(b.y),
                 Fp::raw(b.z), Fp::raw(b.w), Fp::raw(c.x), Fp::raw(c.y), Fp::raw(c.z), Fp::raw(c.w),
                 Fp::raw(d.x), Fp::raw(d.y), Fp::raw(d.z), Fp::raw(d.w)};

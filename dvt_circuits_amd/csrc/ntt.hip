@@ -39,7 +39,7 @@ __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return b
 // ---------------------------------------------------------------- P1 / P3
 // grid.x = row_stride >> log_cols (tiles along the contiguous axis), grid.y = column
 template <bool INVERSE>
-__global__ void __launch_bounds__(256) ntt_strided_kernel(uint32_t *data, size_t col_stride, uint32_t log_rows,
+__global__ void __launch_bounds__(256) ntt_strided_kernel(const uint32_t *src, uint32_t *data, size_t col_stride, uint32_t log_rows,
                                                          uint32_t row_stride, uint32_t log_cols, uint32_t log_n,
                                                          NttTables tabs) {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -48,13 +48,14 @@ __global__ void __launch_bounds__(256) ntt_strided_kernel(uint32_t *data, size_t
     Fp *sm = reinterpret_cast<Fp *>(lds);
     Fp *tw = sm + tile_elems;  // rows/2 entries: w_rows^e
     uint32_t *col = data + (size_t)blockIdx.y * col_stride;
+    const uint32_t *scol = src + (size_t)blockIdx.y * col_stride;
     const uint32_t c0 = blockIdx.x << log_cols;
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
 
     for (uint32_t e = tid; e < rows / 2; e += nt) tw[e] = root_pow24(tabs, e << (24 - log_rows));
     for (uint32_t idx = tid; idx < tile_elems; idx += nt) {
         uint32_t r = idx >> log_cols, c = idx & cmask;
-        sm[idx] = Fp::raw(col[(size_t)r * row_stride + c0 + c]);
+        sm[idx] = Fp::raw(scol[(size_t)r * row_stride + c0 + c]);
     }
     __syncthreads();
     // forward DIF over the row index
@@ -213,8 +214,10 @@ void ntt_tables_destroy(NttTables *t) {
     t->base = nullptr;
 }
 
-hipError_t launch_coset_lde(hipStream_t st, const NttTables &tabs, uint32_t *d_in, uint32_t *d_out, uint32_t width,
-                            uint32_t log_n, uint32_t shift_mode) {
+hipError_t launch_coset_lde(hipStream_t st, const NttTables &tabs, uint32_t *d_in, uint32_t *d_scratch, uint32_t *d_out,
+                            uint32_t width, uint32_t log_n, uint32_t shift_mode) {
+    // d_scratch ([width][N]) receives the P1 result so that d_in survives; NULL = run P1 in place on d_in.
+    if (!d_scratch) d_scratch = d_in;
     if (width == 0) return hipSuccess;
     if (log_n > 22 || shift_mode > 2) return hipErrorInvalidValue;
     const uint32_t log_n2 = log_n < 12 ? log_n : 12, log_n1 = log_n - log_n2;
@@ -234,17 +237,17 @@ hipError_t launch_coset_lde(hipStream_t st, const NttTables &tabs, uint32_t *d_i
             if (e != hipSuccess) return e;
         }
         dim3 grid((1u << log_n2) >> b, width);
-        ntt_strided_kernel<true><<<grid, 256, lds, st>>>(d_in, n, log_n1, 1u << log_n2, b, log_n, tabs);
+        ntt_strided_kernel<true><<<grid, 256, lds, st>>>(d_in, d_scratch, n, log_n1, 1u << log_n2, b, log_n, tabs);
     }
     {
         size_t lds = ((size_t)(2u << log_n2) + (1u << log_n2)) * 4;
         dim3 grid(1u << log_n1, width);
-        lde_block_kernel<<<grid, 256, lds, st>>>(d_in, d_out, log_n, log_n1, shift_mode, ninv.v, tabs);
+        lde_block_kernel<<<grid, 256, lds, st>>>(log_n1 ? d_scratch : d_in, d_out, log_n, log_n1, shift_mode, ninv.v, tabs);
     }
     if (log_n1) {
         size_t lds = ((size_t)(1u << (log_n1 + b)) + (1u << (log_n1 - 1))) * 4;
         dim3 grid((2u << log_n2) >> b, width);
-        ntt_strided_kernel<false><<<grid, 256, lds, st>>>(d_out, 2 * n, log_n1, 2u << log_n2, b, log_n + 1, tabs);
+        ntt_strided_kernel<false><<<grid, 256, lds, st>>>(d_out, d_out, 2 * n, log_n1, 2u << log_n2, b, log_n + 1, tabs);
     }
     return hipGetLastError();
 }

@@ -1,0 +1,222 @@
+// Generic multi-chip STARK pieces shared by every machine (toy, rv32):
+//   - ConstraintFolder<T,...>: folds a chip's AIR constraints and its LogUp
+//     constraints with powers of alpha.  T = Fp on the gfx950 quotient domain
+//     (K5), T = Fp4 in the host verifier at the out-of-domain point.
+//   - PermRowCtx: evaluates a chip's interactions on one trace row and produces
+//     the LogUp permutation row (K4).
+//   - kernel templates instantiated per generated Air struct (gen/air_*.inc).
+//
+// LogUp layout of a chip with n interactions: nb = ceil(n/2) batch columns then
+// one running-sum column phi, all in F_p^4, stored flattened as 4(nb+1) base
+// columns.  For a batch {j0,j1}: perm_b * d_j0 * d_j1 = s_j0 m_j0 d_j1 + s_j1 m_j1 d_j0
+// with d_j = alpha_p + bus_j + sum_k beta^(k+1) v_jk;  phi is the inclusive prefix
+// sum of the row totals, phi[last] = the chip's cumulative sum.
+// Constraint numbering (powers of alpha): the chip's own constraints 0..C-1, then
+// batch b -> C+b, then phi-first C+nb, phi-transition C+nb+1, phi-last C+nb+2.
+//
+// (stock SP1 keeps this in sp1-stark, absent.)
+#pragma once
+#include "bb.cuh"
+#include "kernels.h"
+
+namespace dvt {
+
+constexpr int WHEN_ALL = 0, WHEN_FIRST = 1, WHEN_LAST = 2, WHEN_TRANS = 3;
+
+DVT_HD Fp4 to_ext(Fp a) { return Fp4::from_base(a); }
+DVT_HD Fp4 to_ext(const Fp4 &a) { return a; }
+
+template <class Air>
+struct PermShape {
+    static constexpr int NB = (Air::N_INTERACTIONS + 1) / 2;
+    static constexpr int EXT_W = Air::N_INTERACTIONS ? NB + 1 : 0;  // ext columns
+    static constexpr int BASE_W = 4 * EXT_W;
+    static constexpr int N_FOLDED = Air::N_CONSTRAINTS + (Air::N_INTERACTIONS ? NB + 3 : 0);
+};
+
+// Access must provide: T main(col,rot), T prep(col,rot), T pub(k),
+//                      Fp4 perm(extcol,rot)   (rot 0 = local, 1 = next)
+template <class Air, class TT, class Access>
+struct ConstraintFolder {
+    using T = TT;
+    using Shape = PermShape<Air>;
+    const Access &ax;
+    const Fp4 *alpha_pows;  // [N_FOLDED]
+    const Fp4 *beta_pows;   // beta^1 .. beta^MAX_ARITY at [0..]
+    Fp4 perm_alpha;
+    T sel_first, sel_last, sel_trans;
+    Fp4 cumsum;
+    Fp4 acc;
+    // pending first half of a LogUp batch
+    T pend_m;
+    Fp4 pend_d;
+
+    DVT_HD ConstraintFolder(const Access &a) : ax(a), acc(Fp4::zero()) {}
+    DVT_HD static T K(uint32_t monty) {
+        if constexpr (sizeof(T) == sizeof(Fp)) return Fp::raw(monty);
+        else return Fp4::from_base(Fp::raw(monty));
+    }
+    DVT_HD T main(int c, int r) const { return ax.main(c, r); }
+    DVT_HD T prep(int c, int r) const { return ax.prep(c, r); }
+    DVT_HD T pub(int k) const { return ax.pub(k); }
+
+    DVT_HD void fold(int idx, const Fp4 &v) { acc += alpha_pows[idx] * v; }
+    DVT_HD void fold_t(int idx, const T &v) { acc += alpha_pows[idx] * v; }
+
+    DVT_HD void constraint(int idx, int when, const T &v) {
+        if (when == WHEN_ALL) fold_t(idx, v);
+        else if (when == WHEN_FIRST) fold_t(idx, v * sel_first);
+        else if (when == WHEN_LAST) fold_t(idx, v * sel_last);
+        else fold_t(idx, v * sel_trans);
+    }
+
+    DVT_HD void interaction(int j, int bus, int sign, int /*scope*/, const T &mult, const T *vals, int n) {
+        Fp4 d = perm_alpha + Fp::from_canonical((uint32_t)bus);
+        for (int k = 0; k < n; k++) d += beta_pows[k] * vals[k];
+        T m = sign > 0 ? mult : -mult;
+        if ((j & 1) == 0) {
+            pend_m = m;
+            pend_d = d;
+            if (j == Air::N_INTERACTIONS - 1) {  // odd tail: perm * d - m = 0
+                Fp4 p = ax.perm(j >> 1, 0);
+                fold(Air::N_CONSTRAINTS + (j >> 1), p * d - to_ext(m));
+            }
+        } else {
+            Fp4 p = ax.perm(j >> 1, 0);
+            Fp4 lhs = p * pend_d * d;
+            Fp4 rhs = d * pend_m + pend_d * m;
+            fold(Air::N_CONSTRAINTS + (j >> 1), lhs - rhs);
+        }
+    }
+
+    DVT_HD void finish_logup() {
+        if (Air::N_INTERACTIONS == 0) return;
+        constexpr int NB = Shape::NB;
+        Fp4 phi_l = ax.perm(NB, 0), phi_n = ax.perm(NB, 1);
+        Fp4 sum_l = Fp4::zero(), sum_n = Fp4::zero();
+        for (int b = 0; b < NB; b++) { sum_l += ax.perm(b, 0); sum_n += ax.perm(b, 1); }
+        const int base = Air::N_CONSTRAINTS + NB;
+        fold(base + 0, (phi_l - sum_l) * sel_first);
+        fold(base + 1, (phi_n - phi_l - sum_n) * sel_trans);
+        fold(base + 2, (phi_l - cumsum) * sel_last);
+    }
+
+    DVT_HD Fp4 run() {
+        Air::constraints(*this);
+        Air::interactions(*this);
+        finish_logup();
+        return acc;
+    }
+};
+
+#if defined(__HIPCC__)
+// ------------------------------------------------------------------ K4: permutation trace
+struct PermArgs {
+    const uint32_t *main;  // [MAIN_W][N]
+    const uint32_t *prep;  // [PREP_W][N]
+    const uint32_t *pub;   // device public values (Montgomery)
+    uint32_t *perm;        // [4*EXT_W][N] out
+    const Fp4 *beta_pows;  // device
+    Fp4 perm_alpha;
+    uint32_t log_n;
+};
+
+template <class Air>
+struct PermRowCtx {
+    using T = Fp;
+    const PermArgs &a;
+    size_t n, row;
+    Fp4 batch, total;
+    __device__ PermRowCtx(const PermArgs &args, size_t r) : a(args), n((size_t)1 << args.log_n), row(r), batch(Fp4::zero()), total(Fp4::zero()) {}
+    __device__ static T K(uint32_t m) { return Fp::raw(m); }
+    __device__ T main(int c, int r) const { return Fp::raw(a.main[(size_t)c * n + ((row + r) & (n - 1))]); }
+    __device__ T prep(int c, int r) const { return Fp::raw(a.prep[(size_t)c * n + ((row + r) & (n - 1))]); }
+    __device__ T pub(int k) const { return Fp::raw(a.pub[k]); }
+    __device__ void store_ext(int extcol, const Fp4 &v) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) a.perm[((size_t)(4 * extcol + k)) * n + row] = v.c[k].v;
+    }
+    __device__ void interaction(int j, int bus, int sign, int /*scope*/, const T &mult, const T *vals, int nv) {
+        Fp4 d = a.perm_alpha + Fp::from_canonical((uint32_t)bus);
+        for (int k = 0; k < nv; k++) d += a.beta_pows[k] * vals[k];
+        Fp4 term = mult.is_zero() ? Fp4::zero() : inv(d) * (sign > 0 ? mult : -mult);
+        if ((j & 1) == 0) batch = term; else batch += term;
+        if ((j & 1) || j == Air::N_INTERACTIONS - 1) {
+            store_ext(j >> 1, batch);
+            total += batch;
+        }
+    }
+};
+
+template <class Air>
+__global__ void __launch_bounds__(256) perm_rows_kernel(PermArgs a) {
+    size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= ((size_t)1 << a.log_n)) return;
+    PermRowCtx<Air> ctx(a, row);
+    Air::interactions(ctx);
+    ctx.store_ext(PermShape<Air>::NB, ctx.total);  // row total; the scan turns it into phi
+}
+
+// ------------------------------------------------------------------ K5: quotient
+struct QuotientArgs {
+    const uint32_t *main_lde;  // [MAIN_W][2N]
+    const uint32_t *prep_lde;  // [PREP_W][2N]
+    const uint32_t *perm_lde;  // [4*EXT_W][2N]
+    const uint32_t *pub;
+    uint32_t *out;             // two chunks: [2][4][N]  (even rows, odd rows)
+    const Fp4 *alpha_pows;
+    const Fp4 *beta_pows;
+    Fp4 perm_alpha, cumsum;
+    Fp zinv_even, zinv_odd;    // 1 / Z_H(x) on even / odd LDE rows
+    Fp z_even, z_odd;          // Z_H(x) itself
+    Fp w_inv;                  // omega_N^-1
+    uint32_t log_n;
+    NttTables tabs;
+};
+
+struct QuotAccess {
+    const QuotientArgs &a;
+    size_t m, i, inext;
+    __device__ Fp main(int c, int r) const { return Fp::raw(a.main_lde[(size_t)c * m + (r ? inext : i)]); }
+    __device__ Fp prep(int c, int r) const { return Fp::raw(a.prep_lde[(size_t)c * m + (r ? inext : i)]); }
+    __device__ Fp pub(int k) const { return Fp::raw(a.pub[k]); }
+    __device__ Fp4 perm(int e, int r) const {
+        Fp4 v;
+        size_t at = r ? inext : i;
+#pragma unroll
+        for (int k = 0; k < 4; k++) v.c[k] = Fp::raw(a.perm_lde[(size_t)(4 * e + k) * m + at]);
+        return v;
+    }
+};
+
+template <class Air>
+__global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
+    const size_t m = (size_t)2 << a.log_n;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    QuotAccess ax{a, m, i, (i + 2) & (m - 1)};
+    ConstraintFolder<Air, Fp, QuotAccess> f(ax);
+    f.alpha_pows = a.alpha_pows;
+    f.beta_pows = a.beta_pows;
+    f.perm_alpha = a.perm_alpha;
+    f.cumsum = a.cumsum;
+    // x = g * w_{2N}^i
+    const uint32_t log_m = a.log_n + 1;
+    Fp x = Fp::raw(a.tabs.sh_lo[1]) * (Fp::raw(a.tabs.tw_hi[((uint32_t)i << (24 - log_m)) >> 12]) *
+                                        Fp::raw(a.tabs.tw_lo[((uint32_t)i << (24 - log_m)) & 4095]));
+    const bool odd = i & 1;
+    Fp zh = odd ? a.z_odd : a.z_even, zhinv = odd ? a.zinv_odd : a.zinv_even;
+    Fp d1 = x - Fp::one(), d2 = x - a.w_inv;
+    Fp pinv = inv(d1 * d2);
+    f.sel_first = zh * (pinv * d2);
+    f.sel_last = zh * (pinv * d1);
+    f.sel_trans = d2;
+    Fp4 q = f.run() * zhinv;
+    const size_t n = m >> 1;
+    uint32_t *o = a.out + (odd ? 4 * n : 0) + (i >> 1);
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[(size_t)k * n] = q.c[k].v;
+}
+#endif  // __HIPCC__
+
+}  // namespace dvt

@@ -14,14 +14,16 @@
  *     reference's 92 test vectors observe as process exit code 1, script/run.sh:82-89);
  *     DVT_ERR_INPUT = malformed argument / ELF / proof; DVT_ERR_DEVICE = HIP failure
  *     or no gfx950 device (there is NO CPU fallback); DVT_ERR_UNSUPPORTED = the
- *     program uses an instruction the prover has no chip for yet.
+ *     program uses an instruction the prover has no chip for yet;
+ *     DVT_ERR_REJECTED = a proof failed verification.
  *   - buffers returned through `uint8_t **` are library-allocated, release with dvt_free().
  *   - a dvt_prover is re-entrant per handle: one handle per caller thread (the
  *     reference's HTTP node calls prove() from concurrent tokio workers,
- *     src/service/node.rs:72-81), or serialise calls on a shared handle.
+ *     src/service/node.rs:72-81); calls on one handle are serialised internally.
  *   - "device field array": uint32_t words in HBM holding BabyBear elements in
  *     the library's internal (Montgomery) representation, COLUMN-MAJOR
  *     ([width][height], element (r,c) at c*height + r), natural row order.
+ *   - all device work of a handle runs on the handle's own HIP stream (dvt_stream).
  */
 #ifndef DVT_PROVER_H
 #define DVT_PROVER_H
@@ -36,12 +38,14 @@ extern "C" {
 #define DVT_ERR_INPUT 2
 #define DVT_ERR_DEVICE 3
 #define DVT_ERR_UNSUPPORTED 4
+#define DVT_ERR_REJECTED 5
 
 typedef struct dvt_prover dvt_prover;
+typedef struct dvt_pk dvt_pk;
 
 /* ---------------------------------------------------------------- lifecycle */
 /* ProverClient::from_env() (src/main.rs:438,461,481).  cfg_json may be NULL or
- * a JSON object: {"device":0,"log_shard_size":21,"fri_queries":100,"pow_bits":16}. */
+ * a JSON object: {"device":0,"fri_queries":100,"pow_bits":16,"profile":0}. */
 int dvt_prover_create(const char *cfg_json, dvt_prover **out);
 void dvt_prover_destroy(dvt_prover *p);
 /* last error text of this handle (or of the failed create when p == NULL) */
@@ -49,26 +53,28 @@ const char *dvt_last_error(const dvt_prover *p);
 void dvt_free(void *ptr);
 /* ABI version of this header */
 uint32_t dvt_abi_version(void);
+/* the handle's hipStream_t (for event timing by the caller) */
+void *dvt_stream(dvt_prover *p);
+int dvt_sync(dvt_prover *p);
 
 /* ------------------------------------------------- stage-level entry points
  * One call = one kernel family of SURVEY.md section 8(a) on caller-owned device
  * memory; used by the parity tests and by bench.py's roofline measurement.
- * `stream` is a hipStream_t (NULL = the handle's own stream).  Asynchronous:
- * call dvt_sync() before reading results on the host. */
-int dvt_sync(dvt_prover *p, void *stream);
+ * Asynchronous on dvt_stream(p): call dvt_sync() before reading results. */
 /* canonical <-> internal representation, in place, n words */
-int dvt_dev_to_internal(dvt_prover *p, void *stream, uint32_t *d_words, size_t n);
-int dvt_dev_from_internal(dvt_prover *p, void *stream, uint32_t *d_words, size_t n);
+int dvt_dev_to_internal(dvt_prover *p, uint32_t *d_words, size_t n);
+int dvt_dev_from_internal(dvt_prover *p, uint32_t *d_words, size_t n);
 
 /* K1: coset low-degree extension, blow-up 2.  d_in [width][2^log_n] holds
  * evaluations over the subgroup H; d_out [width][2^(log_n+1)] receives the
  * evaluations on shift*H', |H'| = 2|H|.  shift_mode: 0 = the generator 31 (trace
- * commitments), 1 = 1, 2 = w_{2N}^-1 (the two quotient chunks).  d_in is used
- * as scratch and is clobbered.  log_n <= 22. */
-int dvt_stage_coset_lde(dvt_prover *p, void *stream, uint32_t *d_in, uint32_t *d_out,
+ * commitments), 1 = 1, 2 = w_{2N}^-1 (the two quotient chunks).  d_scratch
+ * ([width][2^log_n]) holds the intermediate of the first pass when log_n > 12;
+ * pass NULL to run that pass in place, which clobbers d_in.  log_n <= 22. */
+int dvt_stage_coset_lde(dvt_prover *p, uint32_t *d_in, uint32_t *d_scratch, uint32_t *d_out,
                         uint32_t width, uint32_t log_n, uint32_t shift_mode);
 
-/* K2+K3: mixed-height Poseidon2 Merkle commitment. */
+/* K2+K3: mixed-height Poseidon2 Merkle commitment (natural-order pairing). */
 typedef struct {
     const uint32_t *d_data; /* device field array [width][2^log_height] */
     uint32_t width;
@@ -77,10 +83,38 @@ typedef struct {
 /* words the digest buffer must hold: (2*H - 1) * 8, H = tallest height */
 size_t dvt_merkle_digest_words(const dvt_dev_matrix *mats, size_t n);
 /* d_digests: layer 0 (H digests of 8 words) first, then H/2, ..., the root last */
-int dvt_stage_merkle_commit(dvt_prover *p, void *stream, const dvt_dev_matrix *mats, size_t n,
-                            uint32_t *d_digests);
+int dvt_stage_merkle_commit(dvt_prover *p, const dvt_dev_matrix *mats, size_t n, uint32_t *d_digests);
 /* raw permutation on n states of 16 words each (device array [n][16]); test hook */
-int dvt_stage_poseidon2_permute(dvt_prover *p, void *stream, uint32_t *d_states, size_t n);
+int dvt_stage_poseidon2_permute(dvt_prover *p, uint32_t *d_states, size_t n);
+
+/* K8: one FRI fold of d_v (2^log_m extension elements, 4 words each, natural
+ * order) into d_out (2^(log_m-1)); d_ro (may be NULL) is added element-wise;
+ * beta = 4 canonical words. */
+int dvt_stage_fri_fold(dvt_prover *p, const uint32_t *d_v, uint32_t *d_out, const uint32_t *d_ro,
+                       const uint32_t beta[4], uint32_t log_m);
+
+/* ------------------------------------------------- machine-level entry points
+ * A "machine" is a fixed list of chips (AIRs) compiled into the library:
+ * "toy" (engine unit tests) and "rv32" (the RISC-V core machine).  Traces are
+ * host arrays, canonical form, column-major. */
+typedef struct {
+    uint32_t chip_id;
+    uint32_t log_n;
+    const uint32_t *data; /* [width][2^log_n] */
+} dvt_host_trace;
+/* preprocessed commitment = the prover half of client.setup(elf) (src/main.rs:462) */
+int dvt_machine_setup(dvt_prover *p, const char *machine, const dvt_host_trace *prep, size_t nprep,
+                      dvt_pk **pk, uint8_t **vk, size_t *vk_len);
+void dvt_pk_free(dvt_prover *p, dvt_pk *pk);
+/* prove one shard from explicit main traces (sorted by chip id) */
+int dvt_machine_prove(dvt_prover *p, const dvt_pk *pk, const dvt_host_trace *main, size_t nmain,
+                      const uint32_t *public_values, size_t npub, uint8_t **proof, size_t *proof_len);
+/* host-only; DVT_ERR_REJECTED + reason in *reason (release with dvt_free) when the proof is bad */
+int dvt_machine_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, size_t proof_len,
+                       uint32_t fri_queries, uint32_t pow_bits, char **reason);
+/* per-stage milliseconds of the last dvt_machine_prove on this handle (needs "profile":1):
+ * out[0..5] = commit_main, permutation, quotient, openings, fri, total */
+int dvt_last_stage_ms(dvt_prover *p, float out[6]);
 
 #ifdef __cplusplus
 }

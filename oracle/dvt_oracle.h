@@ -46,7 +46,8 @@ typedef struct {
 } orc_matrix;
 /* Commit to `n` matrices.  digests must hold (2*H - 1)*8 words where H is the
  * tallest height: layer 0 (H digests) first, then H/2, ... , 1 (the root last).
- * Matrices of equal height are hashed in argument order. */
+ * Matrices of equal height are hashed in argument order.  Pairing is natural-order:
+ * parent i of a layer of L nodes = compress(child i, child i + L). */
 void orc_merkle_commit(const orc_matrix *mats, size_t n, uint32_t *digests);
 /* words needed for `digests` */
 size_t orc_merkle_digest_words(const orc_matrix *mats, size_t n);

@@ -3,7 +3,10 @@
  * Mixed-height Merkle commitment over Poseidon2 (SURVEY.md section 8(a) rows K2/K3;
  * in stock SP1 this is p3-merkle-tree's field MMCS, source absent):
  *   layer 0   : digest[r] = sponge(row r of every tallest matrix, concatenated)
- *   layer k+1 : digest[i] = compress(prev[2i], prev[2i+1]); when matrices of
+ *   layer k+1 : digest[i] = compress(prev[i], prev[i + L]) with L = |layer k+1|
+ *               (natural-order pairing: row r of a matrix of height H and row
+ *               r mod L of a matrix of height L share a path, which is exactly the
+ *               relation natural-order FRI folding needs); when matrices of
  *               exactly that height exist, digest[i] = compress(digest[i],
  *               sponge(their rows i, concatenated))
  * Heights are powers of two.  Natural row order. */
@@ -47,7 +50,7 @@ void orc_merkle_commit(const orc_matrix *mats, size_t n, uint32_t *digests) {
         int inject = 0;
         for (size_t m = 0; m < n; m++) if (mats[m].log_height == lh) inject = 1;
         for (size_t i = 0; i < L; i++) {
-            orc_compress(prev + 16 * i, prev + 16 * i + 8, cur + 8 * i);
+            orc_compress(prev + 8 * i, prev + 8 * (i + L), cur + 8 * i);
             if (inject) {
                 uint32_t hr[8];
                 size_t k = gather_rows(mats, n, lh, i, buf);

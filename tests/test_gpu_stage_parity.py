@@ -173,5 +173,5 @@ def test_merkle_full_size_root_of_subtrees(gpu, oracle):
     lvl = layers[off : off + (1 << (lh - 10))]
     cur = [x for x in lvl]
     while len(cur) > 1:
-        cur = [oracle.compress(cur[2 * i], cur[2 * i + 1]) for i in range(len(cur) // 2)]
+        cur = [oracle.compress(cur[i], cur[i + len(cur) // 2]) for i in range(len(cur) // 2)]
     assert (layers[-1] == cur[0]).all()

@@ -146,10 +146,10 @@ def test_merkle_commit_structure(oracle):
     assert layers.shape == (31, 8)
     leaf = [oracle.hash_slice(np.concatenate([a[:, r], b[:, r]])) for r in range(16)]
     assert (layers[:16] == np.array(leaf)).all()
-    l8 = [oracle.compress(leaf[2 * i], leaf[2 * i + 1]) for i in range(8)]
+    l8 = [oracle.compress(leaf[i], leaf[i + 8]) for i in range(8)]
     assert (layers[16:24] == np.array(l8)).all()
-    l4 = [oracle.compress(oracle.compress(l8[2 * i], l8[2 * i + 1]), oracle.hash_slice(c[:, i])) for i in range(4)]
+    l4 = [oracle.compress(oracle.compress(l8[i], l8[i + 4]), oracle.hash_slice(c[:, i])) for i in range(4)]
     assert (layers[24:28] == np.array(l4)).all()
-    l2 = [oracle.compress(l4[2 * i], l4[2 * i + 1]) for i in range(2)]
+    l2 = [oracle.compress(l4[i], l4[i + 2]) for i in range(2)]
     root = oracle.compress(oracle.compress(l2[0], l2[1]), oracle.hash_slice(d[:, 0]))
     assert (layers[30] == root).all()
