@@ -18,7 +18,7 @@ def test_header_symbols_exported(prover_lib):
     assert len(names) >= 10
     for n in names:
         assert hasattr(prover_lib, n), f"{n} declared in include/dvt_prover.h but not exported"
-    assert prover_lib.dvt_abi_version() == 1
+    assert prover_lib.dvt_abi_version() >= 2
 
 
 def test_create_without_gpu_fails_loudly(prover_lib):
