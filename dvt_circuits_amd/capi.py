@@ -72,8 +72,85 @@ def load():
     lib.dvt_machine_prove.argtypes = [vp, vp, C.POINTER(HostTrace), sz, u32p, sz, C.POINTER(u8p), C.POINTER(sz)]
     lib.dvt_machine_verify.argtypes = [C.c_char_p, sz, C.c_char_p, sz, u32, u32, C.POINTER(C.c_char_p)]
     lib.dvt_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.dvt_setup.argtypes = [vp, C.c_char_p, sz, C.POINTER(vp), C.POINTER(u8p), C.POINTER(sz)]
+    lib.dvt_execute.argtypes = [C.c_char_p, sz, C.POINTER(Buf), sz, C.c_uint64, C.POINTER(u8p), C.POINTER(sz), C.POINTER(Report), C.POINTER(C.c_char_p)]
+    lib.dvt_prove_core.argtypes = [vp, vp, C.POINTER(Buf), sz, C.POINTER(u8p), C.POINTER(sz), C.POINTER(Report)]
+    lib.dvt_verify.argtypes = [C.c_char_p, sz, C.c_char_p, sz, u32, u32, C.POINTER(C.c_int32), C.POINTER(u8p), C.POINTER(sz), C.POINTER(C.c_char_p)]
+    lib.dvt_rv32_debug_traces.argtypes = [C.c_char_p, sz, C.POINTER(Buf), sz, C.POINTER(u32p), C.POINTER(sz), C.POINTER(C.c_char_p)]
     _lib = lib
     return lib
+
+
+class Buf(C.Structure):
+    _fields_ = [("data", C.c_char_p), ("len", C.c_size_t)]
+
+
+class Report(C.Structure):
+    _fields_ = [("cycles", C.c_uint64), ("exit_code", C.c_int32), ("halted", C.c_uint32), ("unprovable", C.c_uint32)]
+
+
+def _bufs(stdin):
+    arr = (Buf * max(len(stdin), 1))()
+    for i, b in enumerate(stdin):
+        arr[i] = Buf(bytes(b), len(b))
+    return arr
+
+
+def _take_str(lib, p):
+    s = p.value.decode() if p.value else ""
+    if p.value:
+        lib.dvt_free(C.cast(p, C.c_void_p))
+    return s
+
+
+def execute(elf: bytes, stdin=(), max_cycles=0):
+    """Host-only emulation (reference src/main.rs:430-447).  Returns (rc, report dict, public_values, error text)."""
+    lib = load()
+    pv, n, rep, err = u8p(), C.c_size_t(), Report(), C.c_char_p()
+    rc = lib.dvt_execute(elf, len(elf), _bufs(stdin), len(stdin), max_cycles, C.byref(pv), C.byref(n), C.byref(rep), C.byref(err))
+    out = C.string_at(pv, n.value) if pv else b""
+    if pv:
+        lib.dvt_free(C.cast(pv, C.c_void_p))
+    return rc, dict(cycles=rep.cycles, exit_code=rep.exit_code, halted=bool(rep.halted), unprovable=bool(rep.unprovable)), out, _take_str(lib, err)
+
+
+def verify(vk: bytes, proof: bytes, fri_queries=100, pow_bits=16):
+    """Host-only verification of a core proof.  Returns (ok, exit_code, public_values, reason)."""
+    lib = load()
+    ec, pv, n, why = C.c_int32(), u8p(), C.c_size_t(), C.c_char_p()
+    rc = lib.dvt_verify(vk, len(vk), proof, len(proof), fri_queries, pow_bits, C.byref(ec), C.byref(pv), C.byref(n), C.byref(why))
+    out = C.string_at(pv, n.value) if pv else b""
+    if pv:
+        lib.dvt_free(C.cast(pv, C.c_void_p))
+    return rc == DVT_OK, ec.value, out, _take_str(lib, why)
+
+
+def rv32_debug_traces(elf: bytes, stdin=()):
+    """Host-only: the traces the prover would commit.  Returns (chips, pubs) where
+    chips = list of dict(chip_id, log_n, main [w][n], prep [w][n])."""
+    lib = load()
+    blob, n, err = u32p(), C.c_size_t(), C.c_char_p()
+    rc = lib.dvt_rv32_debug_traces(elf, len(elf), _bufs(stdin), len(stdin), C.byref(blob), C.byref(n), C.byref(err))
+    if rc:
+        raise DvtError(rc, _take_str(lib, err))
+    w = np.ctypeslib.as_array(blob, shape=(n.value,)).copy()
+    lib.dvt_free(C.cast(blob, C.c_void_p))
+    nch = int(w[0])
+    meta = w[1:1 + 4 * nch].reshape(nch, 4)
+    at = 1 + 4 * nch
+    npub = int(w[at])
+    pubs = w[at + 1:at + 1 + npub].copy()
+    at += 1 + npub
+    chips = []
+    for cid, lg, mw, pw in meta:
+        h = 1 << int(lg)
+        main = w[at:at + int(mw) * h].reshape(int(mw), h)
+        at += int(mw) * h
+        prep = w[at:at + int(pw) * h].reshape(int(pw), h)
+        at += int(pw) * h
+        chips.append(dict(chip_id=int(cid), log_n=int(lg), main=main, prep=prep))
+    assert at == len(w)
+    return chips, pubs
 
 
 def _traces(traces):
@@ -186,6 +263,21 @@ class Prover:
         b = C.string_at(out, n.value)
         self.lib.dvt_free(C.cast(out, C.c_void_p))
         return b
+
+    # ---- the reference's boundary (src/main.rs:461-474)
+    def setup(self, elf: bytes):
+        pk, vk, n = C.c_void_p(), u8p(), C.c_size_t()
+        self.check(self.lib.dvt_setup(self.h, elf, len(elf), C.byref(pk), C.byref(vk), C.byref(n)))
+        vkb = C.string_at(vk, n.value)
+        self.lib.dvt_free(C.cast(vk, C.c_void_p))
+        return pk, vkb
+
+    def prove_core(self, pk, stdin=()):
+        out, n, rep = u8p(), C.c_size_t(), Report()
+        self.check(self.lib.dvt_prove_core(self.h, pk, _bufs(stdin), len(stdin), C.byref(out), C.byref(n), C.byref(rep)))
+        b = C.string_at(out, n.value)
+        self.lib.dvt_free(C.cast(out, C.c_void_p))
+        return b, dict(cycles=rep.cycles, exit_code=rep.exit_code, halted=bool(rep.halted))
 
     def stage_ms(self):
         out = (C.c_float * 6)()

@@ -11,6 +11,7 @@
 #include <string>
 
 #include "engine.h"
+#include "rv32.h"
 
 using namespace dvt;
 
@@ -22,6 +23,9 @@ struct dvt_prover {
 };
 struct dvt_pk {
     ProvingKey key;
+    bool is_rv32 = false;
+    rv32::Program prog;
+    rv32::HostPrep prep;
 };
 
 static thread_local std::string g_create_err;
@@ -77,10 +81,12 @@ static std::vector<uint32_t> vk_words(const VerifyingKey &vk) {
     w.dg(vk.prep_root);
     w.u32((uint32_t)vk.prep_chips.size());
     for (auto &c : vk.prep_chips) { w.u32((uint32_t)c.chip_id); w.u32(c.log_n); }
+    w.u32((uint32_t)vk.extra.size());
+    for (auto x : vk.extra) w.u32(x);
     return w.w;
 }
 static bool vk_parse(const uint8_t *b, size_t len, VerifyingKey *vk) {
-    if (len % 4 || len < 4 * 14) return false;
+    if (len % 4 || len < 4 * 15) return false;
     std::vector<uint32_t> wv(len / 4);
     memcpy(wv.data(), b, len);
     try {
@@ -99,6 +105,9 @@ static bool vk_parse(const uint8_t *b, size_t len, VerifyingKey *vk) {
             if (c.chip_id < 0 || c.chip_id >= vk->machine->n_chips || c.log_n > 22) return false;
             vk->prep_chips.push_back(c);
         }
+        uint32_t ne = r.len(16);
+        for (uint32_t i = 0; i < ne; i++) vk->extra.push_back(r.u32());
+        if (r.p != r.end) return false;
     } catch (const std::exception &) { return false; }
     return true;
 }
@@ -341,6 +350,222 @@ int dvt_last_stage_ms(dvt_prover *p, float out[6]) {
     if (!p || !out) return DVT_ERR_INPUT;
     const StageTimes &t = p->eng.times;
     out[0] = t.commit_main; out[1] = t.perm; out[2] = t.quotient; out[3] = t.open; out[4] = t.fri; out[5] = t.total;
+    return DVT_OK;
+}
+
+}  // extern "C"
+
+// ====================================================================== rv32 boundary
+namespace {
+constexpr uint32_t CORE_PROOF_MAGIC = 0x31435644u;  // "DVC1"
+constexpr uint64_t SINGLE_SHARD_MAX_CYCLES = 1ull << 22;
+
+std::vector<std::vector<uint8_t>> collect_stdin(const dvt_buf *bufs, size_t n) {
+    std::vector<std::vector<uint8_t>> v(n);
+    for (size_t i = 0; i < n; i++)
+        if (bufs[i].len) v[i].assign(bufs[i].data, bufs[i].data + bufs[i].len);
+    return v;
+}
+void fill_report(dvt_report *rep, const rv32::ExecResult &r) {
+    if (!rep) return;
+    rep->cycles = r.cycles;
+    rep->exit_code = r.halted ? r.exit_code : -1;
+    rep->halted = r.halted;
+    rep->unprovable = r.unsupported;
+}
+uint8_t *dup_bytes(const std::vector<uint8_t> &v, size_t *len) {
+    uint8_t *b = (uint8_t *)malloc(v.size() + 1);
+    if (b && !v.empty()) memcpy(b, v.data(), v.size());
+    if (len) *len = v.size();
+    return b;
+}
+}  // namespace
+
+extern "C" {
+
+int dvt_setup(dvt_prover *p, const uint8_t *elf, size_t elf_len, dvt_pk **pk_out, uint8_t **vk, size_t *vk_len) {
+    if (!p || !elf || !pk_out) return fail(p, DVT_ERR_INPUT, "null argument");
+    std::lock_guard<std::mutex> lk(p->mu);
+    dvt_pk *pk = new dvt_pk();
+    std::string err;
+    if (!rv32::load_elf(elf, elf_len, &pk->prog, &err)) { delete pk; return fail(p, DVT_ERR_INPUT, "ELF: %s", err.c_str()); }
+    rv32::build_prep(pk->prog, &pk->prep);
+    pk->is_rv32 = true;
+    std::vector<ChipRef> refs;
+    std::vector<std::vector<uint32_t>> host;
+    for (int c : {RV32_CHIP_PROGRAM, RV32_CHIP_BYTE, RV32_CHIP_MEM_IMAGE}) {
+        refs.push_back({c, pk->prep.log_n[c]});
+        host.push_back(pk->prep.prep[c]);
+    }
+    if (!p->eng.setup(machine_rv32(), refs, host, &pk->key)) {
+        p->eng.free_key(&pk->key);
+        delete pk;
+        return fail(p, DVT_ERR_DEVICE, "%s", p->eng.err.c_str());
+    }
+    pk->key.vk.extra = {pk->prog.entry};
+    if (vk && vk_len) {
+        *vk = copy_out(vk_words(pk->key.vk), vk_len);
+        if (!*vk) { p->eng.free_key(&pk->key); delete pk; return fail(p, DVT_ERR_DEVICE, "out of host memory"); }
+    }
+    *pk_out = pk;
+    return DVT_OK;
+}
+
+int dvt_execute(const uint8_t *elf, size_t elf_len, const dvt_buf *stdin_bufs, size_t nbuf, uint64_t max_cycles,
+                uint8_t **public_values, size_t *pv_len, dvt_report *report, char **err_text) {
+    if (err_text) *err_text = nullptr;
+    if (public_values) *public_values = nullptr;
+    if (!elf || (nbuf && !stdin_bufs)) return DVT_ERR_INPUT;
+    rv32::Program prog;
+    std::string err;
+    if (!rv32::load_elf(elf, elf_len, &prog, &err)) {
+        if (err_text) *err_text = strdup(("ELF: " + err).c_str());
+        return DVT_ERR_INPUT;
+    }
+    rv32::ExecResult res;
+    rv32::execute(prog, collect_stdin(stdin_bufs, nbuf), false, max_cycles ? max_cycles : ~0ull, &res);
+    fill_report(report, res);
+    if (public_values) *public_values = dup_bytes(res.public_values, pv_len);
+    if (!res.error.empty()) {
+        if (err_text) *err_text = strdup(res.error.c_str());
+        return DVT_ERR_GUEST;
+    }
+    if (res.exit_code != 0) {
+        if (err_text) *err_text = strdup("guest halted with a non-zero exit code");
+        return DVT_ERR_GUEST;
+    }
+    return DVT_OK;
+}
+
+int dvt_prove_core(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_bufs, size_t nbuf, uint8_t **proof, size_t *proof_len,
+                   dvt_report *report) {
+    if (!p || !pk || !proof || !proof_len || (nbuf && !stdin_bufs)) return fail(p, DVT_ERR_INPUT, "null argument");
+    if (!pk->is_rv32) return fail(p, DVT_ERR_INPUT, "proving key was not made by dvt_setup");
+    std::lock_guard<std::mutex> lk(p->mu);
+    HIP_TRY(p, hipSetDevice(p->eng.device));
+    rv32::ExecResult res;
+    rv32::execute(pk->prog, collect_stdin(stdin_bufs, nbuf), true, SINGLE_SHARD_MAX_CYCLES, &res);
+    fill_report(report, res);
+    if (!res.error.empty()) return fail(p, DVT_ERR_GUEST, "guest trapped: %s", res.error.c_str());
+    if (res.exit_code != 0) return fail(p, DVT_ERR_GUEST, "guest halted with exit code %d", res.exit_code);
+    if (res.unsupported) return fail(p, DVT_ERR_UNSUPPORTED, "no chip for %s", res.unsupported_what.c_str());
+    rv32::HostTraces T;
+    std::string err;
+    if (!rv32::build_traces_host(pk->prog, res, pk->prep, &T, &err)) return fail(p, DVT_ERR_UNSUPPORTED, "%s", err.c_str());
+    const MachineDesc *m = machine_rv32();
+    std::vector<uint32_t *> dev(m->n_chips, nullptr);
+    std::vector<ChipTrace> traces;
+    auto cleanup = [&] { for (auto d : dev) if (d) (void)hipFree(d); };
+    for (int c = 0; c < m->n_chips; c++) {
+        size_t words = T.main[c].size();
+        if (hipMalloc(&dev[c], words * 4) != hipSuccess || hipMemcpy(dev[c], T.main[c].data(), words * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            launch_to_internal(p->eng.stream, dev[c], words) != hipSuccess) {
+            cleanup();
+            return fail(p, DVT_ERR_DEVICE, "uploading trace of chip %s failed", m->chips[c].name);
+        }
+        traces.push_back({c, T.log_n[c], dev[c]});
+    }
+    std::vector<Fp> pubs;
+    for (auto x : T.pubs) pubs.push_back(Fp::from_canonical(x));
+    ShardProof sp;
+    bool ok = p->eng.prove_shard(pk->key, traces, pubs, p->cfg, &sp);
+    (void)hipStreamSynchronize(p->eng.stream);
+    cleanup();
+    if (!ok) return fail(p, DVT_ERR_DEVICE, "%s", p->eng.err.c_str());
+    WordWriter shard;
+    write_shard_proof(shard, sp);
+    WordWriter w;
+    w.u32(CORE_PROOF_MAGIC);
+    w.u32(1);
+    w.u32((uint32_t)res.exit_code);
+    w.u32((uint32_t)res.public_values.size());
+    for (size_t i = 0; i < res.public_values.size(); i += 4) {
+        uint32_t v = 0;
+        for (size_t k = 0; k < 4 && i + k < res.public_values.size(); k++) v |= (uint32_t)res.public_values[i + k] << (8 * k);
+        w.u32(v);
+    }
+    w.u32((uint32_t)shard.w.size());
+    w.w.insert(w.w.end(), shard.w.begin(), shard.w.end());
+    *proof = copy_out(w.w, proof_len);
+    if (!*proof) return fail(p, DVT_ERR_DEVICE, "out of host memory");
+    return DVT_OK;
+}
+
+int dvt_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, size_t proof_len, uint32_t fri_queries, uint32_t pow_bits,
+               int32_t *exit_code, uint8_t **public_values, size_t *pv_len, char **reason) {
+    if (reason) *reason = nullptr;
+    if (public_values) *public_values = nullptr;
+    auto reject = [&](int code, const std::string &why) {
+        if (reason) *reason = strdup(why.c_str());
+        return code;
+    };
+    if (!vk || !proof) return reject(DVT_ERR_INPUT, "null argument");
+    VerifyingKey key;
+    if (!vk_parse(vk, vk_len, &key) || key.machine != machine_rv32() || key.extra.size() != 1) return reject(DVT_ERR_INPUT, "malformed verifying key");
+    if (proof_len % 4) return reject(DVT_ERR_REJECTED, "proof length is not a multiple of 4");
+    std::vector<uint32_t> words(proof_len / 4);
+    memcpy(words.data(), proof, proof_len);
+    StarkConfig cfg;
+    cfg.num_queries = fri_queries;
+    cfg.pow_bits = pow_bits;
+    try {
+        WordReader r(words.data(), words.size());
+        if (r.u32() != CORE_PROOF_MAGIC) return reject(DVT_ERR_REJECTED, "bad container magic");
+        uint32_t nshards = r.len(1 << 20);
+        if (nshards != 1) return reject(DVT_ERR_REJECTED, "multi-shard containers are not produced yet");
+        uint32_t ec = r.u32(), pvl = r.len(1 << 24);
+        std::vector<uint8_t> pv(pvl);
+        for (uint32_t i = 0; i < pvl; i += 4) {
+            uint32_t v = r.u32();
+            for (uint32_t k = 0; k < 4 && i + k < pvl; k++) pv[i + k] = (uint8_t)(v >> (8 * k));
+        }
+        uint32_t nw = r.len(1u << 30);
+        if ((size_t)(r.end - r.p) != nw) return reject(DVT_ERR_REJECTED, "container length mismatch");
+        ShardProof sp = read_shard_proof(r);
+        if (r.p != r.end) return reject(DVT_ERR_REJECTED, "trailing bytes after proof");
+        std::string why = verify_shard(key, sp, cfg);
+        if (!why.empty()) return reject(DVT_ERR_REJECTED, why);
+        // public values of the shard: start pc = the key's entry point, next pc = 0 (halted), exit code as claimed
+        if (sp.public_values.size() < 3) return reject(DVT_ERR_REJECTED, "missing public values");
+        if (sp.public_values[0].canonical() != key.extra[0] % P) return reject(DVT_ERR_REJECTED, "shard does not start at the entry point");
+        if (sp.public_values[1].canonical() != 0) return reject(DVT_ERR_REJECTED, "execution did not halt");
+        if (sp.public_values[2].canonical() != ec % P) return reject(DVT_ERR_REJECTED, "exit code mismatch");
+        if (sp.chips.size() != (size_t)machine_rv32()->n_chips) return reject(DVT_ERR_REJECTED, "every rv32 chip must be present");
+        if (exit_code) *exit_code = (int32_t)ec;
+        if (public_values) *public_values = dup_bytes(pv, pv_len);
+    } catch (const std::exception &e) { return reject(DVT_ERR_REJECTED, e.what()); }
+    return DVT_OK;
+}
+
+int dvt_rv32_debug_traces(const uint8_t *elf, size_t elf_len, const dvt_buf *stdin_bufs, size_t nbuf, uint32_t **blob,
+                          size_t *blob_words, char **err_text) {
+    if (err_text) *err_text = nullptr;
+    if (!elf || !blob || !blob_words) return DVT_ERR_INPUT;
+    auto bad = [&](int code, const std::string &m) { if (err_text) *err_text = strdup(m.c_str()); return code; };
+    rv32::Program prog;
+    std::string err;
+    if (!rv32::load_elf(elf, elf_len, &prog, &err)) return bad(DVT_ERR_INPUT, "ELF: " + err);
+    rv32::HostPrep prep;
+    rv32::build_prep(prog, &prep);
+    rv32::ExecResult res;
+    rv32::execute(prog, collect_stdin(stdin_bufs, nbuf), true, SINGLE_SHARD_MAX_CYCLES, &res);
+    if (!res.error.empty()) return bad(DVT_ERR_GUEST, res.error);
+    rv32::HostTraces T;
+    if (!rv32::build_traces_host(prog, res, prep, &T, &err)) return bad(DVT_ERR_UNSUPPORTED, err);
+    const MachineDesc *m = machine_rv32();
+    std::vector<uint32_t> w;
+    w.push_back((uint32_t)m->n_chips);
+    for (int c = 0; c < m->n_chips; c++) { w.push_back(c); w.push_back(T.log_n[c]); w.push_back(m->chips[c].main_w); w.push_back(m->chips[c].prep_w); }
+    w.push_back((uint32_t)T.pubs.size());
+    w.insert(w.end(), T.pubs.begin(), T.pubs.end());
+    for (int c = 0; c < m->n_chips; c++) {
+        w.insert(w.end(), T.main[c].begin(), T.main[c].end());
+        w.insert(w.end(), prep.prep[c].begin(), prep.prep[c].end());
+    }
+    *blob = (uint32_t *)malloc(w.size() * 4);
+    if (!*blob) return bad(DVT_ERR_DEVICE, "out of host memory");
+    memcpy(*blob, w.data(), w.size() * 4);
+    *blob_words = w.size();
     return DVT_OK;
 }
 

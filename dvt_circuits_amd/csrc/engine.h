@@ -29,6 +29,7 @@ struct VerifyingKey {
     const MachineDesc *machine = nullptr;
     Digest prep_root;                 // all-zero when the machine has no preprocessed chip
     std::vector<ChipRef> prep_chips;  // chips with preprocessed columns (always part of every shard)
+    std::vector<uint32_t> extra;      // machine-specific words bound into the key (rv32: entry pc)
 };
 
 // FRI batching order of the LDE columns of log-height h: every column opened at two

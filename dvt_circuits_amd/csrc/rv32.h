@@ -1,0 +1,214 @@
+// RV32IM guest execution and trace generation for the rv32 machine
+// (tools/airgen/rv32.py).  Stands behind reference src/main.rs:439-442
+// (`client.execute(elf,&stdin).run()`) and the executor half of :463-466.
+//
+// VM contract (this library's own; SP1's lives in the absent sp1-core-executor):
+//   - ELF32 little-endian RISC-V executable; PT_LOAD segments form the initial
+//     memory image, executable segments are decoded into the program table;
+//     registers start at 0; pc starts at e_entry; all addresses < 2^30.
+//   - ecall: t0 = syscall id, a0..a2 = arguments; ids follow the SP1 v3 guest ABI
+//     observed in the reference's bundled guest:
+//     0x00 HALT(a0 = exit code), 0x02 WRITE(fd,ptr,len), 0x10 COMMIT, 0x1A
+//     COMMIT_DEFERRED_PROOFS, 0xF0 HINT_LEN (-> t0), 0xF1 HINT_READ(ptr,len).
+//     stdin is a list of byte buffers (SP1Stdin::write, src/main.rs:434-437).
+//   - instructions without a chip yet (shifts, mulh/mulhsu, div/rem, sub-word
+//     loads/stores) execute, but a program that retires one cannot be proven:
+//     prove returns DVT_ERR_UNSUPPORTED.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "bb.cuh"
+#include "gen/rv32_cols.h"
+
+namespace dvt {
+namespace rv32 {
+
+// flag bit positions, in the FLAGS order of tools/airgen/rv32.py
+enum Flag : uint32_t {
+    F_RD_EN, F_RS1_EN, F_RS2_EN, F_IMM_C, F_ADD, F_SUB, F_AND, F_OR, F_XOR, F_SLT, F_SLTU, F_MUL, F_MULHU,
+    F_LUI, F_JAL, F_JALR, F_BEQ, F_BNE, F_BLT, F_BGE, F_BLTU, F_BGEU, F_LW, F_SW, F_ECALL, N_FLAGS
+};
+constexpr uint32_t B_AND = 1, B_OR = 2, B_XOR = 3, B_LTU = 4, B_MSB = 5, B_RANGE = 6, B_U16 = 7;
+constexpr int N_BYTE_OPS = 7;  // multiplicity columns of the byte chip, in this order: and or xor ltu msb range u16
+constexpr uint32_t ADDR_LIMIT = 1u << 30;
+
+struct Instr {
+    uint32_t pc, rd, rs1, rs2, imm, off, tgt, flags;
+    uint32_t raw;
+    uint8_t supported;  // has a chip (otherwise executes only)
+};
+
+struct Program {
+    uint32_t entry = 0, text_base = 0;
+    std::vector<Instr> instrs;                            // index (pc - text_base) / 4
+    std::vector<std::pair<uint32_t, uint32_t>> image;     // (byte address, word), sorted, word aligned
+};
+
+// One retired instruction, compact (what the host uploads for K0): 12 words.
+struct CycleRec {
+    uint32_t idx;      // instruction index in Program::instrs
+    uint32_t a, b, c;  // rd value written / rs1 value / rs2-or-immediate value
+    uint32_t pa_prev, pa_ts, pb_ts, pc_ts;
+    uint32_t next_pc;
+    uint32_t m_val, m_prev, m_ts;
+};
+
+struct MemInitRow {
+    uint32_t addr, v, f, fts, is_img;
+};
+
+struct ExecResult {
+    int exit_code = -1;
+    bool halted = false;
+    uint64_t cycles = 0;
+    bool unsupported = false;   // retired an instruction the prover has no chip for
+    std::string unsupported_what;
+    std::vector<uint8_t> public_values, stdout_bytes;
+    std::vector<CycleRec> recs;          // filled only when tracing
+    std::vector<MemInitRow> mem_rows;    // sorted by address, filled only when tracing
+    std::string error;                   // non-empty: the guest trapped (bad access, bad pc, ...)
+};
+
+bool load_elf(const uint8_t *elf, size_t n, Program *out, std::string *err);
+// stdin: list of buffers.  trace = keep per-cycle records.  max_cycles bounds the run.
+void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin_bufs, bool trace, uint64_t max_cycles,
+             ExecResult *res);
+
+// ---- trace generation (K0) ---------------------------------------------------
+// Sink interface used by fill_cpu_row:  put(col, canonical value);  byte(op_index, table_row);  prog(idx)
+template <class Sink>
+DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, Sink &s) {
+    const uint32_t fl = in.flags;
+    auto F = [&](uint32_t bit) -> uint32_t { return (fl >> bit) & 1u; };
+    auto B = [](uint32_t w, int i) -> uint32_t { return (w >> (8 * i)) & 0xffu; };
+    const uint32_t clk = 4 * (row + 1);
+    s.put(RV32_CPU_is_real, 1);
+    s.put(RV32_CPU_clk, clk);
+    s.put(RV32_CPU_pc, in.pc);
+    s.put(RV32_CPU_next_pc, r.next_pc);
+    s.put(RV32_CPU_rd, in.rd);
+    s.put(RV32_CPU_rs1, in.rs1);
+    s.put(RV32_CPU_rs2, in.rs2);
+    for (int i = 0; i < 4; i++) {
+        s.put(RV32_CPU_imm_0 + i, B(in.imm, i));
+        s.put(RV32_CPU_off_0 + i, B(in.off, i));
+        s.put(RV32_CPU_a_0 + i, B(r.a, i));
+        s.put(RV32_CPU_b_0 + i, B(r.b, i));
+        s.put(RV32_CPU_c_0 + i, B(r.c, i));
+        s.put(RV32_CPU_pa_prev_0 + i, B(r.pa_prev, i));
+    }
+    s.put(RV32_CPU_tgt, in.tgt);
+    for (uint32_t k = 0; k < N_FLAGS; k++) s.put(RV32_CPU_rd_en + k, F(k));
+    s.prog(r.idx);
+    // register ports
+    uint32_t pb_hi = 0, pc_hi = 0, pa_hi = 0, m_hi = 0;
+    if (F(F_RS2_EN)) {
+        uint32_t d = clk - r.pc_ts - 1;
+        s.put(RV32_CPU_pc_ts, r.pc_ts); s.put(RV32_CPU_pc_lo, d & 0xffff); pc_hi = d >> 16;
+        s.byte(B_U16 - 1, d & 0xffff);
+    }
+    if (F(F_RS1_EN)) {
+        uint32_t d = clk + 1 - r.pb_ts - 1;
+        s.put(RV32_CPU_pb_ts, r.pb_ts); s.put(RV32_CPU_pb_lo, d & 0xffff); pb_hi = d >> 16;
+        s.byte(B_U16 - 1, d & 0xffff);
+    }
+    if (F(F_RD_EN)) {
+        uint32_t d = clk + 3 - r.pa_ts - 1;
+        s.put(RV32_CPU_pa_ts, r.pa_ts); s.put(RV32_CPU_pa_lo, d & 0xffff); pa_hi = d >> 16;
+        s.byte(B_U16 - 1, d & 0xffff);
+    }
+    s.put(RV32_CPU_pb_hi, pb_hi); s.put(RV32_CPU_pc_hi, pc_hi); s.put(RV32_CPU_pa_hi, pa_hi);
+    const int U = RV32_CPU_u_0;
+    const uint32_t a = r.a, b = r.b, c = r.c;
+    if (F(F_ADD) | F(F_SUB)) {
+        // carries of (b + c) for ADD, of (a + c) for SUB
+        uint32_t x = F(F_ADD) ? b : a, cin = 0;
+        for (int i = 0; i < 4; i++) {
+            uint32_t t = B(x, i) + B(c, i) + cin;
+            cin = t >> 8;
+            s.put(U + i, cin);
+        }
+    } else if (F(F_AND) | F(F_OR) | F(F_XOR)) {
+        int op = F(F_AND) ? 0 : F(F_OR) ? 1 : 2;
+        for (int i = 0; i < 4; i++) s.byte(op, (B(b, i) << 8) | B(c, i));
+    } else if (F(F_SLT) | F(F_SLTU) | F(F_BEQ) | F(F_BNE) | F(F_BLT) | F(F_BGE) | F(F_BLTU) | F(F_BGEU)) {
+        const uint32_t sg = F(F_SLT) | F(F_BLT) | F(F_BGE);
+        uint32_t bb[4], cc[4];
+        for (int i = 0; i < 4; i++) { bb[i] = B(b, i); cc[i] = B(c, i); }
+        uint32_t msb_b = sg ? bb[3] >> 7 : 0, msb_c = sg ? cc[3] >> 7 : 0;
+        if (sg) {
+            bb[3] ^= 0x80; cc[3] ^= 0x80;
+            s.byte(B_MSB - 1, B(b, 3) << 8); s.byte(B_MSB - 1, B(c, 3) << 8);
+        }
+        int k = -1;
+        for (int i = 3; i >= 0; i--) if (bb[i] != cc[i]) { k = i; break; }
+        uint32_t bc = k >= 0 ? bb[k] : 0, ccv = k >= 0 ? cc[k] : 0;
+        if (k >= 0) s.put(U + k, 1);
+        s.put(U + 4, bc); s.put(U + 5, ccv);
+        if (k >= 0) s.put(U + 6, inv(Fp::from_canonical(bc) - Fp::from_canonical(ccv)).canonical());
+        s.put(U + 7, bc < ccv);
+        s.put(U + 8, msb_b); s.put(U + 9, msb_c);
+        s.byte(B_LTU - 1, (bc << 8) | ccv);
+    } else if (F(F_MUL) | F(F_MULHU)) {
+        uint32_t acc = 0;
+        for (int k = 0; k < 8; k++) {
+            for (int i = 0; i < 4; i++) { int j = k - i; if (j >= 0 && j < 4) acc += B(b, i) * B(c, j); }
+            s.put(U + k, acc & 0xff);
+            s.put(U + 8 + k, acc >> 8);
+            s.byte(B_U16 - 1, acc >> 8);
+            acc >>= 8;
+        }
+        uint64_t pr = (uint64_t)b * c;
+        for (int k = 0; k < 4; k++) s.byte(B_RANGE - 1, (((uint32_t)(pr >> (16 * k)) & 0xff) << 8) | ((uint32_t)(pr >> (16 * k + 8)) & 0xff));
+    } else if (F(F_LW) | F(F_SW) | F(F_JALR)) {
+        uint32_t sum = b + in.off, cin = 0;
+        for (int i = 0; i < 4; i++) {
+            uint32_t t = B(b, i) + B(in.off, i) + cin;
+            cin = t >> 8;
+            s.put(U + i, t & 0xff);
+            s.put(U + 4 + i, cin);
+        }
+        s.byte(B_RANGE - 1, (B(sum, 0) << 8) | B(sum, 1));
+        s.byte(B_RANGE - 1, (B(sum, 2) << 8) | B(sum, 3));
+        s.byte(B_LTU - 1, (B(sum, 3) << 8) | 0x40);
+        if (F(F_JALR)) {
+            s.put(U + 8, sum & 1);
+        } else {
+            for (int i = 0; i < 4; i++) { s.put(U + 8 + i, B(r.m_val, i)); s.put(U + 12 + i, B(r.m_prev, i)); }
+            uint32_t d = clk + 2 - r.m_ts - 1;
+            s.put(U + 16, r.m_ts); s.put(U + 17, d & 0xffff); m_hi = d >> 16;
+            s.put(U + 18, m_hi);
+            s.byte(B_U16 - 1, d & 0xffff);
+            s.byte(B_AND - 1, (B(sum, 0) << 8) | 3);
+        }
+    } else if (F(F_ECALL)) {
+        uint32_t idc = b % P;
+        s.put(U + 0, idc == 0);
+        if (idc) s.put(U + 1, inv(Fp::from_canonical(idc)).canonical());
+    }
+    s.byte(B_RANGE - 1, (pb_hi << 8) | pc_hi);
+    s.byte(B_RANGE - 1, (pa_hi << 8) | m_hi);
+    if (F(F_ADD) | F(F_SUB) | F(F_MUL) | F(F_MULHU) | F(F_ECALL)) {
+        s.byte(B_RANGE - 1, (B(a, 0) << 8) | B(a, 1));
+        s.byte(B_RANGE - 1, (B(a, 2) << 8) | B(a, 3));
+    }
+}
+
+// Host-side trace bundle of one shard (canonical, column-major), for the debug C-ABI and tests.
+struct HostTraces {
+    uint32_t log_n[5];
+    std::vector<uint32_t> main[5];
+    std::vector<uint32_t> pubs;
+};
+// preprocessed traces (program, byte, mem_image) for setup
+struct HostPrep {
+    uint32_t log_n[5];
+    std::vector<uint32_t> prep[5];
+};
+void build_prep(const Program &prog, HostPrep *out);
+bool build_traces_host(const Program &prog, const ExecResult &res, const HostPrep &prep, HostTraces *out, std::string *err);
+
+}  // namespace rv32
+}  // namespace dvt

@@ -1,0 +1,426 @@
+// RV32IM ELF loader, decoder, interpreter and host-side trace assembly (see rv32.h).
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <unordered_map>
+
+#include "rv32.h"
+
+namespace dvt {
+namespace rv32 {
+
+// ------------------------------------------------------------------ decode
+static inline uint32_t bits(uint32_t x, int hi, int lo) { return (x >> lo) & ((1u << (hi - lo + 1)) - 1); }
+static inline uint32_t sext(uint32_t v, int b) { return (v & (1u << (b - 1))) ? v | ~((1u << b) - 1) : v; }
+#define FL(x) (1u << (x))
+
+static Instr decode(uint32_t w, uint32_t pc) {
+    Instr in{};
+    in.pc = pc;
+    in.raw = w;
+    in.supported = 1;
+    const uint32_t op = w & 0x7f, rd = bits(w, 11, 7), f3 = bits(w, 14, 12), rs1 = bits(w, 19, 15), rs2 = bits(w, 24, 20), f7 = bits(w, 31, 25);
+    const uint32_t imm_i = sext(bits(w, 31, 20), 12);
+    const uint32_t imm_s = sext((bits(w, 31, 25) << 5) | bits(w, 11, 7), 12);
+    const uint32_t imm_b = sext((bits(w, 31, 31) << 12) | (bits(w, 7, 7) << 11) | (bits(w, 30, 25) << 5) | (bits(w, 11, 8) << 1), 13);
+    const uint32_t imm_u = w & 0xfffff000u;
+    const uint32_t imm_j = sext((bits(w, 31, 31) << 20) | (bits(w, 19, 12) << 12) | (bits(w, 20, 20) << 11) | (bits(w, 30, 21) << 1), 21);
+    auto set_rd = [&] { if (rd) { in.rd = rd; in.flags |= FL(F_RD_EN); } };
+    auto set_rs1 = [&] { in.rs1 = rs1; in.flags |= FL(F_RS1_EN); };
+    auto set_rs2 = [&] { in.rs2 = rs2; in.flags |= FL(F_RS2_EN); };
+    switch (op) {
+    case 0x37: set_rd(); in.imm = imm_u; in.flags |= FL(F_LUI); break;
+    case 0x17: set_rd(); in.imm = pc + imm_u; in.flags |= FL(F_LUI); break;  // AUIPC folded at decode time
+    case 0x6f: set_rd(); in.imm = pc + 4; in.tgt = pc + imm_j; in.flags |= FL(F_JAL); break;
+    case 0x67:
+        if (f3 != 0) { in.supported = 0; break; }
+        set_rd(); set_rs1(); in.imm = pc + 4; in.off = imm_i; in.flags |= FL(F_JALR);
+        break;
+    case 0x63: {
+        static const int map[8] = {F_BEQ, F_BNE, -1, -1, F_BLT, F_BGE, F_BLTU, F_BGEU};
+        if (map[f3] < 0) { in.supported = 0; break; }
+        set_rs1(); set_rs2(); in.tgt = pc + imm_b; in.flags |= FL(map[f3]);
+        break;
+    }
+    case 0x03:
+        set_rd(); set_rs1(); in.off = imm_i;
+        if (f3 == 2) in.flags |= FL(F_LW); else in.supported = 0;
+        break;
+    case 0x23:
+        set_rs1(); set_rs2(); in.off = imm_s;
+        if (f3 == 2) in.flags |= FL(F_SW); else in.supported = 0;
+        break;
+    case 0x13: {
+        set_rd(); set_rs1(); in.imm = imm_i; in.flags |= FL(F_IMM_C);
+        static const int map[8] = {F_ADD, -1, F_SLT, F_SLTU, F_XOR, -1, F_OR, F_AND};
+        if (map[f3] < 0) { in.supported = 0; in.imm = rs2; } else in.flags |= FL(map[f3]);
+        break;
+    }
+    case 0x33: {
+        set_rd(); set_rs1(); set_rs2();
+        int fam = -1;
+        if (f7 == 0x00) { static const int m0[8] = {F_ADD, -1, F_SLT, F_SLTU, F_XOR, -1, F_OR, F_AND}; fam = m0[f3]; }
+        else if (f7 == 0x20) { fam = f3 == 0 ? F_SUB : -1; }
+        else if (f7 == 0x01) { fam = f3 == 0 ? F_MUL : f3 == 3 ? F_MULHU : -1; }
+        if (fam < 0) in.supported = 0; else in.flags |= FL(fam);
+        break;
+    }
+    case 0x73:
+        if (w == 0x00000073u) {  // ecall: a (t0) <- advice, b = t0, c = a0
+            in.rd = 5; in.rs1 = 5; in.rs2 = 10;
+            in.flags |= FL(F_ECALL) | FL(F_RD_EN) | FL(F_RS1_EN) | FL(F_RS2_EN);
+        } else in.supported = 0;
+        break;
+    case 0x0f: in.supported = 0; break;  // fence
+    default: in.supported = 0; break;
+    }
+    return in;
+}
+
+// ------------------------------------------------------------------ ELF
+static uint32_t rd32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+static uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+bool load_elf(const uint8_t *elf, size_t n, Program *out, std::string *err) {
+    auto bad = [&](const char *m) { if (err) *err = m; return false; };
+    if (!elf || n < 52 || memcmp(elf, "\x7f" "ELF", 4) != 0) return bad("not an ELF file");
+    if (elf[4] != 1 || elf[5] != 1) return bad("not ELF32 little-endian");
+    if (rd16(elf + 18) != 243) return bad("not a RISC-V ELF");
+    Program p;
+    p.entry = rd32(elf + 24);
+    uint32_t phoff = rd32(elf + 28), phentsize = rd16(elf + 42), phnum = rd16(elf + 44);
+    if (phentsize < 32 || (uint64_t)phoff + (uint64_t)phentsize * phnum > n) return bad("bad program headers");
+    std::map<uint32_t, uint32_t> image;
+    bool have_text = false;
+    for (uint32_t r = 0; r < 32; r++) image[r] = 0;  // registers live at word addresses 0..31, initial value 0
+    for (uint32_t i = 0; i < phnum; i++) {
+        const uint8_t *ph = elf + phoff + (size_t)i * phentsize;
+        if (rd32(ph) != 1) continue;  // PT_LOAD
+        uint32_t off = rd32(ph + 4), vaddr = rd32(ph + 8), filesz = rd32(ph + 16), memsz = rd32(ph + 20), flags = rd32(ph + 24);
+        if ((uint64_t)off + filesz > n || filesz > memsz) return bad("segment outside file");
+        if (vaddr % 4 || vaddr < 32 || (uint64_t)vaddr + memsz > ADDR_LIMIT) return bad("segment address not word aligned or out of range (< 2^30)");
+        for (uint32_t k = 0; k < memsz; k += 4) {
+            uint32_t w = 0;
+            for (uint32_t b = 0; b < 4; b++)
+                if (k + b < filesz) w |= (uint32_t)elf[off + k + b] << (8 * b);
+            image[vaddr + k] = w;
+        }
+        if (flags & 1) {  // executable
+            if (have_text) return bad("more than one executable segment");
+            have_text = true;
+            p.text_base = vaddr;
+            uint32_t words = (filesz + 3) / 4;
+            p.instrs.resize(words);
+            for (uint32_t k = 0; k < words; k++) p.instrs[k] = decode(image[vaddr + 4 * k], vaddr + 4 * k);
+        }
+    }
+    if (!have_text) return bad("no executable segment");
+    if (p.entry < p.text_base || p.entry >= p.text_base + 4 * p.instrs.size() || p.entry % 4) return bad("entry point outside text");
+    p.image.assign(image.begin(), image.end());
+    *out = std::move(p);
+    return true;
+}
+
+// ------------------------------------------------------------------ interpreter
+namespace {
+struct Cell { uint32_t val, ts; uint8_t touched, img; uint32_t init; };
+struct Memory {
+    static constexpr uint32_t PAGE_BITS = 10;
+    std::unordered_map<uint32_t, std::vector<Cell>> pages;
+    Cell &at(uint32_t addr) {  // addr: word-aligned byte address (or register index 0..31 scaled by caller)
+        uint32_t w = addr >> 2, pg = w >> PAGE_BITS;
+        auto it = pages.find(pg);
+        if (it == pages.end()) it = pages.emplace(pg, std::vector<Cell>(1u << PAGE_BITS, Cell{0, 0, 0, 0, 0})).first;
+        return it->second[w & ((1u << PAGE_BITS) - 1)];
+    }
+};
+}  // namespace
+
+void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin_bufs, bool trace, uint64_t max_cycles,
+             ExecResult *res) {
+    ExecResult &R = *res;
+    R = ExecResult();
+    Memory mem;  // guest memory, keyed by byte address; registers are kept separately (addresses 0..31 of the AIR)
+    Cell regs[32];
+    for (auto &c : regs) c = Cell{0, 0, 0, 0, 0};
+    for (auto &kv : prog.image)
+        if (kv.first >= 32) { Cell &c = mem.at(kv.first); c.val = c.init = kv.second; c.img = 1; }
+    size_t next_input = 0;
+    uint32_t pc = prog.entry;
+    const size_t ninstr = prog.instrs.size();
+    auto trap = [&](const std::string &m) { R.error = m + " at pc 0x" + [&] { char b[16]; snprintf(b, sizeof b, "%x", pc); return std::string(b); }(); };
+    while (R.cycles < max_cycles) {
+        if (pc < prog.text_base || pc % 4 || (pc - prog.text_base) / 4 >= ninstr) { trap("pc outside text"); return; }
+        const uint32_t idx = (pc - prog.text_base) / 4;
+        const Instr &in = prog.instrs[idx];
+        const uint32_t w = in.raw, fl = in.flags;
+        const uint32_t clk = 4 * (uint32_t)((trace ? R.recs.size() : 0) + 1);
+        CycleRec rec{};
+        rec.idx = idx;
+        uint32_t next_pc = pc + 4, a = 0, b = 0, c = 0;
+        if (!in.supported) {
+            // executes but cannot be proven: plain interpreter semantics
+            if (!R.unsupported) { char bb[64]; snprintf(bb, sizeof bb, "instruction 0x%08x at pc 0x%x", w, pc); R.unsupported_what = bb; }
+            R.unsupported = true;
+            const uint32_t op = w & 0x7f, rd = bits(w, 11, 7), f3 = bits(w, 14, 12), rs1 = bits(w, 19, 15), rs2 = bits(w, 24, 20), f7 = bits(w, 31, 25);
+            uint32_t x = regs[rs1].val, y = regs[rs2].val, out = 0;
+            bool wr = true;
+            if (op == 0x13 || op == 0x33) {
+                uint32_t sh = (op == 0x13 ? rs2 : y) & 31;
+                if (op == 0x33 && f7 == 0x01) {
+                    int64_t sx = (int32_t)x, sy = (int32_t)y;
+                    switch (f3) {
+                    case 1: out = (uint32_t)((sx * sy) >> 32); break;
+                    case 2: out = (uint32_t)((sx * (int64_t)(uint64_t)y) >> 32); break;
+                    case 4: out = y == 0 ? 0xffffffffu : (x == 0x80000000u && y == 0xffffffffu) ? x : (uint32_t)((int32_t)x / (int32_t)y); break;
+                    case 5: out = y == 0 ? 0xffffffffu : x / y; break;
+                    case 6: out = y == 0 ? x : (x == 0x80000000u && y == 0xffffffffu) ? 0 : (uint32_t)((int32_t)x % (int32_t)y); break;
+                    case 7: out = y == 0 ? x : x % y; break;
+                    default: trap("illegal instruction"); return;
+                    }
+                } else if (f3 == 1) out = x << sh;
+                else if (f3 == 5) out = (bits(w, 30, 30)) ? (uint32_t)((int32_t)x >> sh) : x >> sh;
+                else { trap("illegal instruction"); return; }
+            } else if (op == 0x03 || op == 0x23) {
+                uint32_t addr = x + (op == 0x03 ? sext(bits(w, 31, 20), 12) : sext((bits(w, 31, 25) << 5) | bits(w, 11, 7), 12));
+                if (addr < 32 || addr >= ADDR_LIMIT) { trap("memory access out of range"); return; }
+                Cell &cell = mem.at(addr & ~3u);
+                uint32_t sh = 8 * (addr & 3);
+                if (op == 0x03) {
+                    uint32_t v = cell.val >> sh;
+                    switch (f3) {
+                    case 0: out = sext(v & 0xff, 8); break;
+                    case 1: if (addr & 1) { trap("misaligned load"); return; } out = sext(v & 0xffff, 16); break;
+                    case 4: out = v & 0xff; break;
+                    case 5: if (addr & 1) { trap("misaligned load"); return; } out = v & 0xffff; break;
+                    default: trap("illegal load"); return;
+                    }
+                } else {
+                    wr = false;
+                    if (f3 == 0) cell.val = (cell.val & ~(0xffu << sh)) | ((y & 0xff) << sh);
+                    else if (f3 == 1) { if (addr & 1) { trap("misaligned store"); return; } cell.val = (cell.val & ~(0xffffu << sh)) | ((y & 0xffff) << sh); }
+                    else { trap("illegal store"); return; }
+                }
+            } else if (op == 0x0f) { wr = false; }
+            else { trap("illegal instruction"); return; }
+            if (wr && rd) regs[rd].val = out;
+            pc = next_pc;
+            R.cycles++;
+            continue;
+        }
+        // ---- provable instruction: accesses in port order c (rs2), b (rs1), memory, a (rd)
+        if (fl & FL(F_RS2_EN)) { Cell &r2 = regs[in.rs2]; c = r2.val; rec.pc_ts = r2.ts; r2.ts = clk; r2.touched = 1; }
+        if (fl & FL(F_IMM_C)) c = in.imm;
+        if (fl & FL(F_RS1_EN)) { Cell &r1 = regs[in.rs1]; b = r1.val; rec.pb_ts = r1.ts; r1.ts = clk + 1; r1.touched = 1; }
+        if (fl & (FL(F_ADD))) a = b + c;
+        else if (fl & FL(F_SUB)) a = b - c;
+        else if (fl & FL(F_AND)) a = b & c;
+        else if (fl & FL(F_OR)) a = b | c;
+        else if (fl & FL(F_XOR)) a = b ^ c;
+        else if (fl & FL(F_SLT)) a = (int32_t)b < (int32_t)c;
+        else if (fl & FL(F_SLTU)) a = b < c;
+        else if (fl & FL(F_MUL)) a = b * c;
+        else if (fl & FL(F_MULHU)) a = (uint32_t)(((uint64_t)b * c) >> 32);
+        else if (fl & FL(F_LUI)) a = in.imm;
+        else if (fl & FL(F_JAL)) { a = in.imm; next_pc = in.tgt; }
+        else if (fl & FL(F_JALR)) {
+            a = in.imm;
+            uint32_t t = b + in.off;
+            if (t >= ADDR_LIMIT) { trap("jump target out of range"); return; }
+            next_pc = t & ~1u;
+        } else if (fl & (FL(F_BEQ) | FL(F_BNE) | FL(F_BLT) | FL(F_BGE) | FL(F_BLTU) | FL(F_BGEU))) {
+            bool t = (fl & FL(F_BEQ)) ? b == c : (fl & FL(F_BNE)) ? b != c : (fl & FL(F_BLT)) ? (int32_t)b < (int32_t)c
+                   : (fl & FL(F_BGE)) ? (int32_t)b >= (int32_t)c : (fl & FL(F_BLTU)) ? b < c : b >= c;
+            if (t) next_pc = in.tgt;
+        } else if (fl & (FL(F_LW) | FL(F_SW))) {
+            uint32_t addr = b + in.off;
+            if (addr < 32 || addr >= ADDR_LIMIT) { trap("memory access out of range"); return; }
+            if (addr & 3) { trap("misaligned word access"); return; }
+            Cell &cell = mem.at(addr);
+            if (!cell.touched) { cell.touched = 1; cell.init = cell.val; }
+            rec.m_prev = cell.val;
+            rec.m_ts = cell.ts;
+            if (fl & FL(F_SW)) cell.val = c; else a = cell.val;
+            rec.m_val = cell.val;
+            cell.ts = clk + 2;
+        } else if (fl & FL(F_ECALL)) {
+            // b = t0 (id), c = a0
+            uint32_t a1 = regs[11].val, a2 = regs[12].val;
+            a = b;  // t0 unchanged unless the call returns a value
+            switch (b) {
+            case 0x00: R.halted = true; R.exit_code = (int)c; next_pc = 0; break;
+            case 0x02: {  // WRITE(fd = a0, ptr = a1, len = a2)
+                for (uint32_t k = 0; k < a2; k++) {
+                    uint32_t ad = a1 + k;
+                    if (ad < 32 || ad >= ADDR_LIMIT) { trap("WRITE buffer out of range"); return; }
+                    uint8_t by = (uint8_t)(mem.at(ad & ~3u).val >> (8 * (ad & 3)));
+                    if (c == 3) R.public_values.push_back(by); else R.stdout_bytes.push_back(by);
+                }
+                break;
+            }
+            case 0x10: case 0x1a: break;  // COMMIT / COMMIT_DEFERRED_PROOFS: digest words (binding to public values: next round)
+            case 0xf0: a = next_input < stdin_bufs.size() ? (uint32_t)stdin_bufs[next_input].size() : 0; break;
+            case 0xf1: {  // HINT_READ(ptr = a0, len = a1): the words become initial memory (must be untouched so far)
+                if (next_input >= stdin_bufs.size()) { trap("HINT_READ with no input left"); return; }
+                const auto &buf = stdin_bufs[next_input++];
+                if (a1 != buf.size()) { trap("HINT_READ length mismatch"); return; }
+                if (c % 4 || c < 32 || (uint64_t)c + a1 > ADDR_LIMIT) { trap("HINT_READ pointer misaligned or out of range"); return; }
+                for (uint32_t k = 0; k < a1; k += 4) {
+                    Cell &cell = mem.at(c + k);
+                    if (cell.touched || cell.ts || cell.img) { trap("HINT_READ into the program image or into memory that was already accessed"); return; }
+                    uint32_t wv = 0;
+                    for (uint32_t q = 0; q < 4 && k + q < a1; q++) wv |= (uint32_t)buf[k + q] << (8 * q);
+                    cell.val = wv;
+                }
+                break;
+            }
+            default: trap("unknown syscall"); return;
+            }
+        }
+        if (fl & FL(F_RD_EN)) { Cell &rdc = regs[in.rd]; rec.pa_prev = rdc.val; rec.pa_ts = rdc.ts; rdc.val = a; rdc.ts = clk + 3; rdc.touched = 1; }
+        rec.a = a; rec.b = b; rec.c = c; rec.next_pc = next_pc;
+        if (trace) R.recs.push_back(rec);
+        R.cycles++;
+        pc = next_pc;
+        if (R.halted) break;
+    }
+    if (!R.halted && R.error.empty()) R.error = "cycle limit reached before HALT";
+    if (trace) {
+        // one mem_init row per image word and per touched non-image word, sorted by address
+        std::map<uint32_t, MemInitRow> rows;
+        for (auto &kv : prog.image) {
+            MemInitRow r{kv.first, kv.second, kv.second, 0, 1};
+            if (kv.first < 32) { r.f = regs[kv.first].val; r.fts = regs[kv.first].ts; }
+            rows[kv.first] = r;
+        }
+        for (auto &pg : mem.pages)
+            for (uint32_t k = 0; k < (1u << Memory::PAGE_BITS); k++) {
+                const Cell &cell = pg.second[k];
+                uint32_t addr = ((pg.first << Memory::PAGE_BITS) | k) << 2;
+                auto it = rows.find(addr);
+                if (it != rows.end()) { it->second.f = cell.val; it->second.fts = cell.ts; if (!cell.touched) it->second.f = it->second.v; }
+                else if (cell.touched) rows[addr] = MemInitRow{addr, cell.init, cell.val, cell.ts, 0};
+            }
+        for (auto &kv : rows) R.mem_rows.push_back(kv.second);
+    }
+}
+
+// ------------------------------------------------------------------ preprocessed traces
+static uint32_t ceil_log2(size_t n) { uint32_t l = 0; while (((size_t)1 << l) < n) l++; return l; }
+
+void build_prep(const Program &prog, HostPrep *out) {
+    HostPrep &H = *out;
+    for (auto &l : H.log_n) l = 0;
+    // program: one row per provable instruction, padded by repeating the first row
+    std::vector<const Instr *> rows;
+    for (auto &in : prog.instrs) if (in.supported) rows.push_back(&in);
+    if (rows.empty()) rows.push_back(&prog.instrs[0]);
+    uint32_t lp = ceil_log2(rows.size());
+    size_t np = (size_t)1 << lp;
+    H.log_n[RV32_CHIP_PROGRAM] = lp;
+    auto &P0 = H.prep[RV32_CHIP_PROGRAM];
+    P0.assign((size_t)RV32_PROGRAM_PREP_W * np, 0);
+    for (size_t r = 0; r < np; r++) {
+        const Instr &in = *rows[r < rows.size() ? r : 0];
+        auto put = [&](int col, uint32_t v) { P0[(size_t)col * np + r] = v; };
+        put(RV32_PROGRAM_P_pc, in.pc); put(RV32_PROGRAM_P_rd, in.rd); put(RV32_PROGRAM_P_rs1, in.rs1); put(RV32_PROGRAM_P_rs2, in.rs2);
+        for (int i = 0; i < 4; i++) { put(RV32_PROGRAM_P_imm_0 + i, (in.imm >> (8 * i)) & 0xff); put(RV32_PROGRAM_P_off_0 + i, (in.off >> (8 * i)) & 0xff); }
+        put(RV32_PROGRAM_P_tgt, in.tgt);
+        for (uint32_t k = 0; k < N_FLAGS; k++) put(RV32_PROGRAM_P_rd_en + k, (in.flags >> k) & 1);
+    }
+    // byte table
+    H.log_n[RV32_CHIP_BYTE] = 16;
+    auto &B0 = H.prep[RV32_CHIP_BYTE];
+    const size_t nb = 65536;
+    B0.assign((size_t)RV32_BYTE_PREP_W * nb, 0);
+    for (uint32_t r = 0; r < nb; r++) {
+        uint32_t b = r >> 8, c = r & 0xff;
+        B0[(size_t)RV32_BYTE_P_b * nb + r] = b; B0[(size_t)RV32_BYTE_P_c * nb + r] = c;
+        B0[(size_t)RV32_BYTE_P_and * nb + r] = b & c; B0[(size_t)RV32_BYTE_P_or * nb + r] = b | c;
+        B0[(size_t)RV32_BYTE_P_xor * nb + r] = b ^ c; B0[(size_t)RV32_BYTE_P_ltu * nb + r] = b < c;
+        B0[(size_t)RV32_BYTE_P_msb * nb + r] = b >> 7;
+    }
+    // memory image
+    uint32_t li = ceil_log2(prog.image.size());
+    size_t ni = (size_t)1 << li;
+    H.log_n[RV32_CHIP_MEM_IMAGE] = li;
+    auto &I0 = H.prep[RV32_CHIP_MEM_IMAGE];
+    I0.assign((size_t)RV32_MEM_IMAGE_PREP_W * ni, 0);
+    for (size_t r = 0; r < prog.image.size(); r++) {
+        I0[(size_t)RV32_MEM_IMAGE_P_addr * ni + r] = prog.image[r].first;
+        for (int i = 0; i < 4; i++) I0[(size_t)(RV32_MEM_IMAGE_P_v_0 + i) * ni + r] = (prog.image[r].second >> (8 * i)) & 0xff;
+        I0[(size_t)RV32_MEM_IMAGE_P_is_real * ni + r] = 1;
+    }
+}
+
+// ------------------------------------------------------------------ host trace assembly (debug / tests / first path)
+namespace {
+struct HostSink {
+    uint32_t *cpu; size_t n, row;
+    uint32_t *byte_mult; uint32_t *prog_mult;  // byte_mult[op][65536], prog_mult[idx]
+    void put(int col, uint32_t v) { cpu[(size_t)col * n + row] = v; }
+    void byte(int op, uint32_t table_row) { byte_mult[(size_t)op * 65536 + table_row]++; }
+    void prog(uint32_t idx) { prog_mult[idx]++; }
+};
+}  // namespace
+
+bool build_traces_host(const Program &prog, const ExecResult &res, const HostPrep &prep, HostTraces *out, std::string *err) {
+    HostTraces &T = *out;
+    if (res.recs.empty()) { if (err) *err = "no cycles to prove"; return false; }
+    if (res.unsupported) { if (err) *err = "unsupported " + res.unsupported_what; return false; }
+    const uint32_t lc = ceil_log2(res.recs.size());
+    if (lc > 22) { if (err) *err = "shard too long (> 2^22 cycles); multi-shard proving lands next"; return false; }
+    const size_t nc = (size_t)1 << lc;
+    T.log_n[RV32_CHIP_CPU] = lc;
+    T.main[RV32_CHIP_CPU].assign((size_t)RV32_CPU_MAIN_W * nc, 0);
+    std::vector<uint32_t> byte_mult((size_t)N_BYTE_OPS * 65536, 0), prog_idx_mult(prog.instrs.size(), 0);
+    HostSink sink{T.main[RV32_CHIP_CPU].data(), nc, 0, byte_mult.data(), prog_idx_mult.data()};
+    for (size_t r = 0; r < res.recs.size(); r++) {
+        sink.row = r;
+        fill_cpu_row(res.recs[r], prog.instrs[res.recs[r].idx], (uint32_t)r, sink);
+    }
+    // mem_init
+    const uint32_t lm = ceil_log2(res.mem_rows.size());
+    const size_t nm = (size_t)1 << lm;
+    T.log_n[RV32_CHIP_MEM_INIT] = lm;
+    auto &M = T.main[RV32_CHIP_MEM_INIT];
+    M.assign((size_t)RV32_MEM_INIT_MAIN_W * nm, 0);
+    uint32_t prev_addr = 0;
+    for (size_t r = 0; r < res.mem_rows.size(); r++) {
+        const MemInitRow &m = res.mem_rows[r];
+        auto put = [&](int col, uint32_t v) { M[(size_t)col * nm + r] = v; };
+        put(RV32_MEM_INIT_addr, m.addr); put(RV32_MEM_INIT_fts, m.fts); put(RV32_MEM_INIT_is_img, m.is_img); put(RV32_MEM_INIT_is_real, 1);
+        uint32_t d = r ? m.addr - prev_addr - 1 : 0;
+        for (int i = 0; i < 4; i++) {
+            put(RV32_MEM_INIT_v_0 + i, (m.v >> (8 * i)) & 0xff);
+            put(RV32_MEM_INIT_f_0 + i, (m.f >> (8 * i)) & 0xff);
+            put(RV32_MEM_INIT_d_0 + i, (d >> (8 * i)) & 0xff);
+        }
+        sink.byte(B_RANGE - 1, ((d & 0xff) << 8) | ((d >> 8) & 0xff));
+        sink.byte(B_RANGE - 1, (((d >> 16) & 0xff) << 8) | (d >> 24));
+        sink.byte(B_LTU - 1, ((d >> 24) << 8) | 0x40);
+        if (!m.is_img) {
+            sink.byte(B_RANGE - 1, ((m.v & 0xff) << 8) | ((m.v >> 8) & 0xff));
+            sink.byte(B_RANGE - 1, (((m.v >> 16) & 0xff) << 8) | (m.v >> 24));
+        }
+        prev_addr = m.addr;
+    }
+    // program multiplicities follow the preprocessed row order (provable instructions only)
+    const uint32_t lp = prep.log_n[RV32_CHIP_PROGRAM];
+    T.log_n[RV32_CHIP_PROGRAM] = lp;
+    T.main[RV32_CHIP_PROGRAM].assign((size_t)1 << lp, 0);
+    {
+        size_t r = 0;
+        for (size_t i = 0; i < prog.instrs.size(); i++)
+            if (prog.instrs[i].supported) T.main[RV32_CHIP_PROGRAM][r++] = prog_idx_mult[i];
+    }
+    T.log_n[RV32_CHIP_BYTE] = 16;
+    T.main[RV32_CHIP_BYTE] = byte_mult;  // [7][65536] already column-major in op order
+    T.log_n[RV32_CHIP_MEM_IMAGE] = prep.log_n[RV32_CHIP_MEM_IMAGE];
+    T.main[RV32_CHIP_MEM_IMAGE].assign((size_t)1 << T.log_n[RV32_CHIP_MEM_IMAGE], 0);
+    T.pubs = {prog.entry % P, res.recs.back().next_pc % P, (uint32_t)res.exit_code % P};
+    return true;
+}
+
+}  // namespace rv32
+}  // namespace dvt

@@ -116,6 +116,45 @@ int dvt_machine_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, s
  * out[0..5] = commit_main, permutation, quotient, openings, fri, total */
 int dvt_last_stage_ms(dvt_prover *p, float out[6]);
 
+/* ------------------------------------------------- the reference's boundary
+ * These five calls are what the reference's FFI for this path binds
+ * (INTEGRATION.md).  ELF = RV32IM guest; stdin = list of byte buffers exactly
+ * as SP1Stdin::write / write_vec push them (src/main.rs:434-437,458-460). */
+typedef struct {
+    const uint8_t *data;
+    size_t len;
+} dvt_buf;
+typedef struct {
+    uint64_t cycles;
+    int32_t exit_code;    /* a0 at HALT; -1 if the guest never halted */
+    uint32_t halted;
+    uint32_t unprovable;  /* retired an instruction without a chip (prove would return DVT_ERR_UNSUPPORTED) */
+} dvt_report;
+/* client.setup(elf) (src/main.rs:462,482): decode the ELF, commit the preprocessed
+ * tables (program, byte, memory image) on the GPU. */
+int dvt_setup(dvt_prover *p, const uint8_t *elf, size_t elf_len, dvt_pk **pk, uint8_t **vk, size_t *vk_len);
+/* client.execute(elf,&stdin).run() (src/main.rs:439-442,498-501): host-only emulation.
+ * Returns DVT_ERR_GUEST when the guest halts with a non-zero exit code or traps
+ * (the reference maps both to process exit code 1).  *public_values = bytes the
+ * guest wrote to fd 3; *err_text (optional) = trap reason; both via dvt_free. */
+int dvt_execute(const uint8_t *elf, size_t elf_len, const dvt_buf *stdin_bufs, size_t nbuf, uint64_t max_cycles,
+                uint8_t **public_values, size_t *pv_len, dvt_report *report, char **err_text);
+/* client.prove(&pk,&stdin).run() (src/main.rs:463-466), SP1 "core" mode: execute,
+ * generate traces, prove on the GPU.  The returned bytes are what proof.save(path)
+ * (src/main.rs:472-474) would write. */
+int dvt_prove_core(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_bufs, size_t nbuf, uint8_t **proof,
+                   size_t *proof_len, dvt_report *report);
+/* stock `client.verify(&proof,&vk)` semantics (NOT the reference's re-execution
+ * `verify` sub-command).  Host-only. */
+int dvt_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, size_t proof_len, uint32_t fri_queries,
+               uint32_t pow_bits, int32_t *exit_code, uint8_t **public_values, size_t *pv_len, char **reason);
+/* test hook, host-only: the traces (canonical, column-major) the prover would
+ * commit for this run.  Layout of *blob (u32 words): n_chips, then per chip
+ * {chip_id, log_n, main_width, prep_width}, then n_pub, pubs..., then per chip the
+ * main words followed by the preprocessed words. */
+int dvt_rv32_debug_traces(const uint8_t *elf, size_t elf_len, const dvt_buf *stdin_bufs, size_t nbuf, uint32_t **blob,
+                          size_t *blob_words, char **err_text);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,6 +105,80 @@ class Oracle:
         return dg.reshape(-1, 8)
 
 
+class ChipAir(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("main_w", C.c_uint32), ("prep_w", C.c_uint32), ("n_pub", C.c_uint32),
+                ("n_constraints", C.c_uint32), ("n_interactions", C.c_uint32), ("max_arity", C.c_uint32),
+                ("when", C.c_void_p), ("inter", C.c_void_p), ("constraints", C.c_void_p), ("interactions", C.c_void_p)]
+
+
+class AirOracle:
+    """Constraint checker + exact LogUp multiset + K4 restatement over the generated C AIRs."""
+
+    def __init__(self, lib, machine: str):
+        self.lib = lib
+        lib.orc_machine.argtypes = [C.c_char_p, C.POINTER(C.c_uint)]
+        lib.orc_machine.restype = C.POINTER(ChipAir)
+        lib.orc_check_constraints.argtypes = [C.POINTER(ChipAir), u32p, u32p, C.c_uint32, u32p, C.POINTER(C.c_int), u32p]
+        lib.orc_check_constraints.restype = C.c_size_t
+        lib.orc_multiset_new.restype = C.c_void_p
+        lib.orc_multiset_free.argtypes = [C.c_void_p]
+        lib.orc_multiset_add_chip.argtypes = [C.c_void_p, C.POINTER(ChipAir), u32p, u32p, C.c_uint32, u32p]
+        lib.orc_multiset_unbalanced.argtypes = [C.c_void_p, u32p, C.c_size_t]
+        lib.orc_multiset_unbalanced.restype = C.c_size_t
+        lib.orc_perm_trace.argtypes = [C.POINTER(ChipAir), u32p, u32p, C.c_uint32, u32p, u32p, u32p, u32p, u32p]
+        n = C.c_uint()
+        self.chips = lib.orc_machine(machine.encode(), C.byref(n))
+        self.nchips = n.value
+        assert self.nchips, machine
+
+    def chip(self, cid):
+        return self.chips[cid]
+
+    @staticmethod
+    def _arr(a):
+        a = np.ascontiguousarray(a, dtype=np.uint32)
+        if a.size == 0:
+            a = np.zeros(1, np.uint32)
+        return a
+
+    def check_constraints(self, cid, main, prep, pubs):
+        main, prep, pubs = self._arr(main), self._arr(prep), self._arr(pubs)
+        log_n = int(main.shape[1]).bit_length() - 1
+        bc, br = C.c_int(-1), C.c_uint32(0)
+        bad = self.lib.orc_check_constraints(C.byref(self.chips[cid]), _ptr(main), _ptr(prep), log_n, _ptr(pubs), C.byref(bc), C.byref(br))
+        return bad, bc.value, br.value
+
+    def logup_unbalanced(self, chips, pubs):
+        """chips: list of dict(chip_id, main, prep).  Returns (count, first offending record)."""
+        ms = self.lib.orc_multiset_new()
+        pubs = self._arr(pubs)
+        for ch in chips:
+            main, prep = self._arr(ch["main"]), self._arr(ch["prep"])
+            log_n = int(ch["main"].shape[1]).bit_length() - 1
+            self.lib.orc_multiset_add_chip(ms, C.byref(self.chips[ch["chip_id"]]), _ptr(main), _ptr(prep), log_n, _ptr(pubs))
+        out = np.zeros(64, np.uint32)
+        n = self.lib.orc_multiset_unbalanced(ms, _ptr(out), out.size)
+        self.lib.orc_multiset_free(ms)
+        return n, out[: 3 + int(out[1])].tolist() if n else None
+
+    def perm_trace(self, cid, main, prep, pubs, alpha, beta):
+        main, prep, pubs = self._arr(main), self._arr(prep), self._arr(pubs)
+        ch = self.chips[cid]
+        n = main.shape[1]
+        log_n = int(n).bit_length() - 1
+        w = 4 * ((ch.n_interactions + 1) // 2 + 1)
+        out = np.zeros((w, n), np.uint32)
+        cs = np.zeros(4, np.uint32)
+        a, b = self._arr(alpha), self._arr(beta)
+        self.lib.orc_perm_trace(C.byref(ch), _ptr(main), _ptr(prep), log_n, _ptr(pubs), _ptr(a), _ptr(b), _ptr(out), _ptr(cs))
+        return out, cs
+
+
+def air(machine: str) -> AirOracle:
+    load()
+    return AirOracle(_cached.lib, machine)
+
+
 _cached = None
 
 

@@ -1,0 +1,190 @@
+"""RV32IM guest programs assembled with tools/rvasm.py for the executor / prover tests
+and the benchmark.  `bignum` is the synthetic "n-participant DKG-like" workload:
+multi-limb multiply-accumulate over 384-bit operands, whose instruction mix
+(add / sltu / lw / mul / mulhu / sw / branches) follows the histogram measured on
+the reference's finalization guest."""
+import struct
+
+from tools.rvasm import Asm, SYS_HINT_LEN, SYS_HINT_READ, SYS_WRITE
+
+M32 = 0xFFFFFFFF
+HEAP = 0x00400000
+
+
+def _write_pv(a, ptr_reg, nbytes):
+    a.li("a0", 3)
+    a.mv("a1", ptr_reg)
+    a.li("a2", nbytes)
+    a.li("t0", SYS_WRITE)
+    a.ecall()
+
+
+def arith():
+    """Every provable instruction on a few operand pairs; results go to public values."""
+    pairs = [(0, 0), (1, M32), (0x80000000, 1), (0x7FFFFFFF, 0x80000000), (0x12345678, 0x9ABCDEF0), (M32, M32), (5, 3), (3, 5)]
+    a = Asm()
+    out = a.dword("out", [0] * (len(pairs) * 16))
+    a.li("s0", out)
+    exp = []
+    sx = lambda v: v - (1 << 32) if v >> 31 else v
+    for x, y in pairs:
+        a.li("a3", x)
+        a.li("a4", y)
+        ops = [("add", (x + y) & M32), ("sub", (x - y) & M32), ("and_", x & y), ("or_", x | y), ("xor", x ^ y),
+               ("slt", int(sx(x) < sx(y))), ("sltu", int(x < y)), ("mul", (x * y) & M32), ("mulhu", (x * y) >> 32)]
+        for name, want in ops:
+            getattr(a, name)("a5", "a3", "a4")
+            a.sw("a5", "s0", 0)
+            a.addi("s0", "s0", 4)
+            exp.append(want)
+        imm = (y & 0x7FF) - (0x400 if y & 1 else 0)
+        for name, want in [("addi", (x + imm) & M32), ("slti", int(sx(x) < imm)), ("sltiu", int(x < (imm & M32))),
+                           ("xori", x ^ (imm & M32)), ("ori", x | (imm & M32)), ("andi", x & (imm & M32))]:
+            getattr(a, name)("a5", "a3", imm)
+            a.sw("a5", "s0", 0)
+            a.addi("s0", "s0", 4)
+            exp.append(want)
+        # branches: record which are taken as a bitmask
+        a.li("a5", 0)
+        for bit, (name, taken) in enumerate([("beq", x == y), ("bne", x != y), ("blt", sx(x) < sx(y)), ("bge", sx(x) >= sx(y)),
+                                             ("bltu", x < y), ("bgeu", x >= y)]):
+            lab = f"t{len(exp)}_{bit}"
+            getattr(a, name)("a3", "a4", lab)
+            a.j(lab + "_n")
+            a.label(lab)
+            a.ori("a5", "a5", 1 << bit)
+            a.label(lab + "_n")
+        a.sw("a5", "s0", 0)
+        a.addi("s0", "s0", 4)
+        exp.append(sum(1 << b for b, t in enumerate([x == y, x != y, sx(x) < sx(y), sx(x) >= sx(y), x < y, x >= y]) if t))
+    # call / return, load back, auipc
+    a.call("fn")
+    a.j("after")
+    a.label("fn")
+    a.lw("a5", "s0", -4)
+    a.addi("a5", "a5", 1)
+    a.ret()
+    a.label("after")
+    a.sw("a5", "s0", 0)
+    exp.append((exp[-1] + 1) & M32)
+    a.li("s1", out)
+    _write_pv(a, "s1", 4 * len(exp))
+    a.halt(0)
+    return a.elf(), b"".join(struct.pack("<I", v) for v in exp)
+
+
+def bignum(iters, limbs=12):
+    """t += a * b (schoolbook, `limbs` x `limbs` words) repeated `iters` times; returns (elf, expected public values)."""
+    A = [(0x9E3779B9 * (i + 1)) & M32 for i in range(limbs)]
+    B = [(0x85EBCA6B * (i + 3) + 7) & M32 for i in range(limbs)]
+    a = Asm()
+    pa, pb = a.dword("a", A), a.dword("b", B)
+    pt = a.dword("t", [0] * (2 * limbs + 1))
+    a.li("s0", iters)
+    a.label("outer")
+    a.li("s1", pb)                 # &b[i]
+    a.li("s2", pt)                 # &t[i]
+    a.li("s3", limbs)              # i counter
+    a.label("row")
+    a.lw("a3", "s1", 0)            # b[i]
+    a.li("s4", pa)                 # &a[j]
+    a.mv("s5", "s2")               # &t[i+j]
+    a.li("s6", limbs)              # j counter
+    a.li("a6", 0)                  # carry
+    a.label("col")
+    a.lw("a4", "s4", 0)            # a[j]
+    a.mul("a5", "a4", "a3")        # lo
+    a.mulhu("a7", "a4", "a3")      # hi
+    a.lw("t1", "s5", 0)            # t[i+j]
+    a.add("t1", "t1", "a5")
+    a.sltu("t2", "t1", "a5")       # c1
+    a.add("t1", "t1", "a6")
+    a.sltu("t3", "t1", "a6")       # c2
+    a.sw("t1", "s5", 0)
+    a.add("a6", "a7", "t2")
+    a.add("a6", "a6", "t3")        # carry = hi + c1 + c2
+    a.addi("s4", "s4", 4)
+    a.addi("s5", "s5", 4)
+    a.addi("s6", "s6", -1)
+    a.bne("s6", "zero", "col")
+    a.lw("t1", "s5", 0)            # propagate the final carry into t[i+limbs]
+    a.add("t1", "t1", "a6")
+    a.sw("t1", "s5", 0)
+    a.addi("s1", "s1", 4)
+    a.addi("s2", "s2", 4)
+    a.addi("s3", "s3", -1)
+    a.bne("s3", "zero", "row")
+    a.addi("s0", "s0", -1)
+    a.bne("s0", "zero", "outer")
+    a.li("s1", pt)
+    _write_pv(a, "s1", 4 * 2 * limbs)
+    a.halt(0)
+    # expected: the same word-level algorithm in Python (the carry out of t[i+limbs] is dropped, as in the guest)
+    t = [0] * (2 * limbs + 1)
+    for _ in range(iters):
+        for i in range(limbs):
+            carry = 0
+            for j in range(limbs):
+                p = A[j] * B[i]
+                lo, hi = p & M32, p >> 32
+                v = (t[i + j] + lo) & M32
+                c1 = int(v < lo)
+                v2 = (v + carry) & M32
+                c2 = int(v2 < carry)
+                t[i + j] = v2
+                carry = (hi + c1 + c2) & M32
+            t[i + limbs] = (t[i + limbs] + carry) & M32
+    exp = b"".join(struct.pack("<I", t[i]) for i in range(2 * limbs))
+    return a.elf(), exp
+
+
+def hint_sum():
+    """Reads one stdin buffer through HINT_LEN / HINT_READ and commits the sum of its words."""
+    a = Asm()
+    res = a.dword("res", [0])
+    a.li("t0", SYS_HINT_LEN)
+    a.ecall()                      # t0 <- length
+    a.mv("s1", "t0")
+    a.li("a0", HEAP)
+    a.mv("a1", "s1")
+    a.li("t0", SYS_HINT_READ)
+    a.ecall()
+    a.li("s2", HEAP)
+    a.add("s3", "s2", "s1")        # end
+    a.li("a5", 0)
+    a.beq("s2", "s3", "done")
+    a.label("loop")
+    a.lw("a4", "s2", 0)
+    a.add("a5", "a5", "a4")
+    a.addi("s2", "s2", 4)
+    a.bltu("s2", "s3", "loop")
+    a.label("done")
+    a.li("s4", res)
+    a.sw("a5", "s4", 0)
+    _write_pv(a, "s4", 4)
+    a.halt(0)
+    return a.elf()
+
+
+def exit_with(code):
+    a = Asm()
+    a.li("a3", 7)
+    a.addi("a3", "a3", 1)
+    a.halt(code)
+    return a.elf()
+
+
+def uses_shift():
+    a = Asm()
+    a.li("a3", 7)
+    a.slli("a3", "a3", 3)
+    a.halt(0)
+    return a.elf()
+
+
+def traps():
+    a = Asm()
+    a.li("a3", 0x1000)
+    a.lw("a4", "a3", 1)            # misaligned
+    a.halt(0)
+    return a.elf()

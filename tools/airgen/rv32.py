@@ -1,0 +1,267 @@
+"""RV32IM core machine (original design; the reference delegates its AIRs to the
+absent sp1-core-machine crate — SURVEY.md sections 0.1 and 8(a)).
+
+Chips
+  program   preprocessed decoded instruction table, one row per instruction word
+  byte      preprocessed 2^16-row byte-pair table: AND/OR/XOR/LTU/MSB/range lookups
+  cpu       one row per executed instruction: fetch (program lookup), register
+            ports (registers live in the memory argument at addresses 0..31),
+            and every instruction family in a shared ("union") column block
+  mem_image preprocessed initial memory image (registers = 0, ELF segments)
+  mem_init  one row per initialised address, sorted: initial value at timestamp 0,
+            final value/timestamp; image words are bound to mem_image
+
+Memory consistency is an offline-checking LogUp multiset over tuples
+(addr, byte0..3, timestamp): every access consumes the previous tuple of its
+address and produces a new one with a strictly larger timestamp.
+Words are 4 byte limbs; all limbs written to a register or to memory are
+range-checked through the byte table.  Addresses are < 2^30.
+
+Timestamps inside a shard: instruction i (0-based) has clk = 4(i+1); it reads
+rs2 at clk, rs1 at clk+1, touches memory at clk+2 and writes rd at clk+3.
+
+DSL conventions: `sel * (...)` gates a family's constraints by its (program-table
+supplied, hence trusted and mutually exclusive) selector.
+"""
+from .dsl import Chip, Expr, Machine, esum, word
+
+BUSES = {"program": 1, "byte": 2, "mem": 3, "image": 4}
+
+# byte-table opcodes
+B_AND, B_OR, B_XOR, B_LTU, B_MSB, B_RANGE, B_U16 = 1, 2, 3, 4, 5, 6, 7
+
+FLAGS = [
+    "rd_en", "rs1_en", "rs2_en", "imm_c",
+    "is_add", "is_sub", "is_and", "is_or", "is_xor", "is_slt", "is_sltu", "is_mul", "is_mulhu",
+    "is_lui", "is_jal", "is_jalr", "is_beq", "is_bne", "is_blt", "is_bge", "is_bltu", "is_bgeu",
+    "is_lw", "is_sw", "is_ecall",
+]
+# instruction tuple on the program bus: pc, rd, rs1, rs2, imm[4], off[4], tgt, flags...
+N_INSTR_FIELDS = 1 + 3 + 4 + 4 + 1 + len(FLAGS)
+
+PUB_START_PC, PUB_NEXT_PC, PUB_EXIT_CODE = 0, 1, 2
+N_PUB = 3
+UNION_W = 20
+
+
+def build_program():
+    ch = Chip("program")
+    fields = [ch.prep("pc"), ch.prep("rd"), ch.prep("rs1"), ch.prep("rs2")]
+    fields += ch.preps("imm", 4) + ch.preps("off", 4) + [ch.prep("tgt")]
+    fields += [ch.prep(f) for f in FLAGS]
+    mult = ch.col("mult")
+    ch.receive("program", fields, mult)
+    return ch
+
+
+def build_byte():
+    ch = Chip("byte")
+    b, c = ch.prep("b"), ch.prep("c")
+    r_and, r_or, r_xor, r_ltu, r_msb = ch.prep("and"), ch.prep("or"), ch.prep("xor"), ch.prep("ltu"), ch.prep("msb")
+    m = {k: ch.col("mult_" + k) for k in ("and", "or", "xor", "ltu", "msb", "range", "u16")}
+    ch.receive("byte", [B_AND, r_and, b, c], m["and"])
+    ch.receive("byte", [B_OR, r_or, b, c], m["or"])
+    ch.receive("byte", [B_XOR, r_xor, b, c], m["xor"])
+    ch.receive("byte", [B_LTU, r_ltu, b, c], m["ltu"])
+    ch.receive("byte", [B_MSB, r_msb, b, c], m["msb"])      # senders use c = 0
+    ch.receive("byte", [B_RANGE, 0, b, c], m["range"])
+    ch.receive("byte", [B_U16, 0, 256 * b + c, 0], m["u16"])
+    return ch
+
+
+def build_cpu():
+    ch = Chip("cpu")
+    is_real, clk, pc, next_pc = ch.col("is_real"), ch.col("clk"), ch.col("pc"), ch.col("next_pc")
+    rd, rs1, rs2 = ch.col("rd"), ch.col("rs1"), ch.col("rs2")
+    imm, off, tgt = ch.cols("imm", 4), ch.cols("off", 4), ch.col("tgt")
+    F = {f: ch.col(f) for f in FLAGS}
+    a, b, c = ch.cols("a", 4), ch.cols("b", 4), ch.cols("c", 4)
+    # register ports: previous timestamp + 24-bit difference (16 + 8 bit limbs)
+    pb_ts, pb_lo, pb_hi = ch.col("pb_ts"), ch.col("pb_lo"), ch.col("pb_hi")
+    pc_ts, pc_lo, pc_hi = ch.col("pc_ts"), ch.col("pc_lo"), ch.col("pc_hi")
+    pa_prev = ch.cols("pa_prev", 4)
+    pa_ts, pa_lo, pa_hi = ch.col("pa_ts"), ch.col("pa_lo"), ch.col("pa_hi")
+    U = ch.cols("u", UNION_W)
+
+    # ---------------- row bookkeeping
+    ch.assert_bool(is_real)
+    ch.assert_zero(is_real.next() * (1 - is_real), "trans")            # real rows first
+    ch.assert_eq(is_real, 1, "first")
+    ch.assert_eq(pc, ch.pub(PUB_START_PC), "first")
+    ch.assert_eq(clk, 4, "first")
+    ch.assert_zero(is_real.next() * (clk.next() - clk - 4), "trans")
+    ch.assert_zero(is_real.next() * (pc.next() - next_pc), "trans")
+    ch.assert_zero((is_real - is_real.next()) * (next_pc - ch.pub(PUB_NEXT_PC)), "trans")
+    ch.assert_zero(is_real * (next_pc - ch.pub(PUB_NEXT_PC)), "last")
+    for f in FLAGS:                                                     # padding rows do nothing
+        ch.assert_zero((1 - is_real) * F[f])
+
+    # ---------------- fetch
+    ch.send("program", [pc, rd, rs1, rs2] + imm + off + [tgt] + [F[f] for f in FLAGS], is_real)
+
+    # ---------------- register ports (memory bus, addresses 0..31)
+    def port(addr, prev_val, val, prev_ts, ts, lo, hi, en):
+        ch.receive("mem", [addr] + prev_val + [prev_ts], en)
+        ch.send("mem", [addr] + val + [ts], en)
+        ch.assert_zero(en * (ts - prev_ts - 1 - lo - 65536 * hi))
+        ch.send("byte", [B_U16, 0, lo, 0], en)
+
+    port(rs2, c, c, pc_ts, clk, pc_lo, pc_hi, F["rs2_en"])
+    port(rs1, b, b, pb_ts, clk + 1, pb_lo, pb_hi, F["rs1_en"])
+    port(rd, pa_prev, a, pa_ts, clk + 3, pa_lo, pa_hi, F["rd_en"])
+    for i in range(4):
+        ch.assert_zero(F["imm_c"] * (c[i] - imm[i]))
+
+    # ---------------- families
+    sel_addsub = F["is_add"] + F["is_sub"]
+    sel_bit = F["is_and"] + F["is_or"] + F["is_xor"]
+    sel_branch = F["is_beq"] + F["is_bne"] + F["is_blt"] + F["is_bge"] + F["is_bltu"] + F["is_bgeu"]
+    sel_signed = F["is_slt"] + F["is_blt"] + F["is_bge"]
+    sel_cmp = F["is_slt"] + F["is_sltu"] + sel_branch
+    sel_mul = F["is_mul"] + F["is_mulhu"]
+    sel_mem = F["is_lw"] + F["is_sw"]
+    sel_adder = sel_mem + F["is_jalr"]
+
+    # ADD / SUB : u[0..3] = carries
+    cy = U[0:4]
+    for i in range(4):
+        cin = cy[i - 1] if i else Expr.const(0)
+        ch.assert_zero(F["is_add"] * (b[i] + c[i] + cin - a[i] - 256 * cy[i]))
+        ch.assert_zero(F["is_sub"] * (a[i] + c[i] + cin - b[i] - 256 * cy[i]))
+        ch.assert_zero(sel_addsub * (cy[i] * (cy[i] - 1)))
+
+    # AND / OR / XOR : four byte lookups
+    op_bit = B_AND * F["is_and"] + B_OR * F["is_or"] + B_XOR * F["is_xor"]
+    for i in range(4):
+        ch.send("byte", [op_bit, a[i], b[i], c[i]], sel_bit)
+
+    # comparator (SLT, SLTU, branches): u[0..3] differing-byte flags, u[4] b_cmp, u[5] c_cmp,
+    # u[6] 1/(b_cmp - c_cmp), u[7] lt, u[8] msb(b3), u[9] msb(c3)
+    df, b_cmp, c_cmp, inv_d, lt, msb_b, msb_c = U[0:4], U[4], U[5], U[6], U[7], U[8], U[9]
+    bt = b[3] + 128 * sel_signed - 256 * msb_b       # top bytes with the sign bit flipped when signed
+    ct = c[3] + 128 * sel_signed - 256 * msb_c
+    bb = b[0:3] + [bt]
+    cc = c[0:3] + [ct]
+    any_df = esum(df)
+    for i in range(4):
+        ch.assert_zero(sel_cmp * (df[i] * (df[i] - 1)))
+        ch.assert_zero(sel_cmp * ((1 - esum(df[i:])) * (bb[i] - cc[i])))   # equal above the flagged byte
+    ch.assert_zero(sel_cmp * (any_df * (any_df - 1)))
+    ch.assert_zero(sel_cmp * (b_cmp - esum(df[i] * bb[i] for i in range(4))))
+    ch.assert_zero(sel_cmp * (c_cmp - esum(df[i] * cc[i] for i in range(4))))
+    ch.assert_zero(sel_cmp * ((b_cmp - c_cmp) * inv_d - any_df))
+    ch.assert_zero((sel_cmp - sel_signed) * msb_b)
+    ch.assert_zero((sel_cmp - sel_signed) * msb_c)
+    ch.send("byte", [B_LTU, lt, b_cmp, c_cmp], sel_cmp)
+    ch.send("byte", [B_MSB, msb_b, b[3], 0], sel_signed)
+    ch.send("byte", [B_MSB, msb_c, c[3], 0], sel_signed)
+    sel_set = F["is_slt"] + F["is_sltu"]
+    ch.assert_zero(sel_set * (a[0] - lt))
+    for i in range(1, 4):
+        ch.assert_zero(sel_set * a[i])
+    is_eq = 1 - any_df
+    taken = (F["is_beq"] * is_eq + F["is_bne"] * (1 - is_eq) + (F["is_blt"] + F["is_bltu"]) * lt
+             + (F["is_bge"] + F["is_bgeu"]) * (1 - lt))
+    ch.assert_zero(sel_branch * (next_pc - pc - 4) - taken * (tgt - pc - 4))
+
+    # MUL / MULHU : u[0..7] product bytes, u[8..15] carries
+    prod, mcy = U[0:8], U[8:16]
+    for k in range(8):
+        terms = esum(b[i] * c[k - i] for i in range(4) if 0 <= k - i < 4)
+        cin = mcy[k - 1] if k else Expr.const(0)
+        ch.assert_zero(sel_mul * (terms + cin - prod[k] - 256 * mcy[k]))
+    for i in range(4):
+        ch.assert_zero(F["is_mul"] * (a[i] - prod[i]))
+        ch.assert_zero(F["is_mulhu"] * (a[i] - prod[4 + i]))
+    for k in range(4):
+        ch.send("byte", [B_RANGE, 0, prod[2 * k], prod[2 * k + 1]], sel_mul)
+    for k in range(8):
+        ch.send("byte", [B_U16, 0, mcy[k], 0], sel_mul)
+
+    # LUI / AUIPC / JAL / JALR link : a := imm   (pc-relative constants are folded at decode time)
+    sel_const = F["is_lui"] + F["is_jal"] + F["is_jalr"]
+    for i in range(4):
+        ch.assert_zero(sel_const * (a[i] - imm[i]))
+    ch.assert_zero(F["is_jal"] * (next_pc - tgt))
+
+    # address adder (LW, SW, JALR): u[0..3] sum bytes, u[4..7] carries
+    s, acy = U[0:4], U[4:8]
+    for i in range(4):
+        cin = acy[i - 1] if i else Expr.const(0)
+        ch.assert_zero(sel_adder * (b[i] + off[i] + cin - s[i] - 256 * acy[i]))
+        ch.assert_zero(sel_adder * (acy[i] * (acy[i] - 1)))
+    ch.send("byte", [B_RANGE, 0, s[0], s[1]], sel_adder)
+    ch.send("byte", [B_RANGE, 0, s[2], s[3]], sel_adder)
+    ch.send("byte", [B_LTU, 1, s[3], 0x40], sel_adder)        # address / target < 2^30
+    # JALR: u[8] = low bit cleared from the target
+    jl = U[8]
+    ch.assert_zero(F["is_jalr"] * (jl * (jl - 1)))
+    ch.assert_zero(F["is_jalr"] * (next_pc - word(s) + jl))
+    # LW / SW: u[8..11] memory value after, u[12..15] before, u[16] prev ts, u[17] lo, u[18] hi
+    mv, mp, m_ts, m_lo, m_hi = U[8:12], U[12:16], U[16], U[17], U[18]
+    ch.send("byte", [B_AND, 0, s[0], 3], sel_mem)             # word aligned
+    ch.receive("mem", [word(s)] + mp + [m_ts], sel_mem)
+    ch.send("mem", [word(s)] + mv + [clk + 2], sel_mem)
+    ch.assert_zero(sel_mem * (clk + 2 - m_ts - 1 - m_lo - 65536 * m_hi))
+    ch.send("byte", [B_U16, 0, m_lo, 0], sel_mem)
+    for i in range(4):
+        ch.assert_zero(F["is_lw"] * (a[i] - mv[i]))
+        ch.assert_zero(F["is_lw"] * (mp[i] - mv[i]))
+        ch.assert_zero(F["is_sw"] * (mv[i] - c[i]))
+    # the 8-bit high limbs of the four timestamp differences, two per lookup
+    ch.send("byte", [B_RANGE, 0, pb_hi, pc_hi], is_real)
+    ch.send("byte", [B_RANGE, 0, pa_hi, m_hi], is_real)      # (u[16..19] belong to the memory family only)
+
+    # range check of a for the families that compute it arithmetically
+    sel_range_a = sel_addsub + sel_mul + F["is_ecall"]
+    ch.send("byte", [B_RANGE, 0, a[0], a[1]], sel_range_a)
+    ch.send("byte", [B_RANGE, 0, a[2], a[3]], sel_range_a)
+
+    # everything that is not a branch / jump / ecall falls through
+    sel_seq = is_real - sel_branch - F["is_jal"] - F["is_jalr"] - F["is_ecall"]
+    ch.assert_zero(sel_seq * (next_pc - pc - 4))
+
+    # ECALL: b = t0 (syscall id), c = a0; a = new t0 (advice).  id 0 = HALT(exit code a0).
+    is_halt, id_inv = U[0], U[1]
+    ec = F["is_ecall"]
+    ch.assert_zero(ec * (is_halt * (is_halt - 1)))
+    ch.assert_zero(ec * (is_halt * word(b)))
+    ch.assert_zero(ec * (word(b) * id_inv - (1 - is_halt)))
+    ch.assert_zero(ec * (next_pc - (1 - is_halt) * (pc + 4)))
+    ch.assert_zero(ec * (is_halt * (word(c) - ch.pub(PUB_EXIT_CODE))))
+    return ch
+
+
+def build_mem_image():
+    ch = Chip("mem_image")
+    addr, v, real = ch.prep("addr"), ch.preps("v", 4), ch.prep("is_real")
+    pad = ch.col("pad")
+    ch.assert_zero(pad)
+    ch.receive("image", [addr] + v, real)
+    return ch
+
+
+def build_mem_init():
+    ch = Chip("mem_init")
+    addr, v, f, fts = ch.col("addr"), ch.cols("v", 4), ch.cols("f", 4), ch.col("fts")
+    d = ch.cols("d", 4)
+    is_img, is_real = ch.col("is_img"), ch.col("is_real")
+    ch.assert_bool(is_real)
+    ch.assert_bool(is_img)
+    ch.assert_zero(is_img * (1 - is_real))
+    ch.assert_zero(is_real.next() * (1 - is_real), "trans")
+    # strictly increasing addresses: addr - prev.addr - 1 = d (4 bytes, < 2^30)
+    ch.assert_zero(is_real.next() * (addr.next() - addr - 1 - word([x.next() for x in d])), "trans")
+    ch.send("byte", [B_RANGE, 0, d[0], d[1]], is_real)
+    ch.send("byte", [B_RANGE, 0, d[2], d[3]], is_real)
+    ch.send("byte", [B_LTU, 1, d[3], 0x40], is_real)
+    ch.send("byte", [B_RANGE, 0, v[0], v[1]], is_real - is_img)
+    ch.send("byte", [B_RANGE, 0, v[2], v[3]], is_real - is_img)
+    ch.send("image", [addr] + v, is_img)
+    ch.send("mem", [addr] + v + [0], is_real)
+    ch.receive("mem", [addr] + f + [fts], is_real)
+    return ch
+
+
+def build():
+    return Machine("rv32", [build_program(), build_byte(), build_cpu(), build_mem_image(), build_mem_init()], BUSES)
