@@ -45,6 +45,12 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc); there is no CPU fallback")
+    try:
+        # PyTorch bundles its own HIP runtime; whichever runtime initialises the GPU first owns it, so
+        # when torch is going to be used in this process (device-memory plumbing) it must be loaded first.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, sz, u32 = C.c_void_p, C.c_size_t, C.c_uint32
     lib.dvt_abi_version.restype = u32
@@ -76,6 +82,10 @@ def load():
     lib.dvt_execute.argtypes = [C.c_char_p, sz, C.POINTER(Buf), sz, C.c_uint64, C.POINTER(u8p), C.POINTER(sz), C.POINTER(Report), C.POINTER(C.c_char_p)]
     lib.dvt_prove_core.argtypes = [vp, vp, C.POINTER(Buf), sz, C.POINTER(u8p), C.POINTER(sz), C.POINTER(Report)]
     lib.dvt_verify.argtypes = [C.c_char_p, sz, C.c_char_p, sz, u32, u32, C.POINTER(C.c_int32), C.POINTER(u8p), C.POINTER(sz), C.POINTER(C.c_char_p)]
+    lib.dvt_rv32_prepare.argtypes = [vp, vp, C.POINTER(Buf), sz, C.POINTER(vp), C.POINTER(Report)]
+    lib.dvt_rv32_prove_job.argtypes = [vp, vp, vp, C.POINTER(u8p), C.POINTER(sz)]
+    lib.dvt_job_free.argtypes = [vp, vp]
+    lib.dvt_job_free.restype = None
     lib.dvt_rv32_debug_traces.argtypes = [C.c_char_p, sz, C.POINTER(Buf), sz, C.POINTER(u32p), C.POINTER(sz), C.POINTER(C.c_char_p)]
     _lib = lib
     return lib
@@ -278,6 +288,46 @@ class Prover:
         b = C.string_at(out, n.value)
         self.lib.dvt_free(C.cast(out, C.c_void_p))
         return b, dict(cycles=rep.cycles, exit_code=rep.exit_code, halted=bool(rep.halted))
+
+    def prepare(self, pk, stdin=()):
+        """host execution + upload; returns (job handle, report)"""
+        job, rep = C.c_void_p(), Report()
+        self.check(self.lib.dvt_rv32_prepare(self.h, pk, _bufs(stdin), len(stdin), C.byref(job), C.byref(rep)))
+        return job, dict(cycles=rep.cycles, exit_code=rep.exit_code, halted=bool(rep.halted))
+
+    def prove_job(self, pk, job, want_bytes=True):
+        """K0..K9 on a prepared, HBM-resident shard"""
+        if not want_bytes:
+            self.check(self.lib.dvt_rv32_prove_job(self.h, pk, job, None, None))
+            return None
+        out, n = u8p(), C.c_size_t()
+        self.check(self.lib.dvt_rv32_prove_job(self.h, pk, job, C.byref(out), C.byref(n)))
+        b = C.string_at(out, n.value)
+        self.lib.dvt_free(C.cast(out, C.c_void_p))
+        return b
+
+    def debug_device_traces(self, pk, job):
+        """K0 on the device, traces downloaded (canonical): list of dict(chip_id, log_n, main), pubs"""
+        self.lib.dvt_rv32_debug_device_traces.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(u32p), C.POINTER(C.c_size_t)]
+        blob, n = u32p(), C.c_size_t()
+        self.check(self.lib.dvt_rv32_debug_device_traces(self.h, pk, job, C.byref(blob), C.byref(n)))
+        w = np.ctypeslib.as_array(blob, shape=(n.value,)).copy()
+        self.lib.dvt_free(C.cast(blob, C.c_void_p))
+        nch = int(w[0])
+        meta = w[1:1 + 4 * nch].reshape(nch, 4)
+        at = 1 + 4 * nch
+        npub = int(w[at])
+        pubs = w[at + 1:at + 1 + npub].copy()
+        at += 1 + npub
+        chips = []
+        for cid, lg, mw, _ in meta:
+            h = 1 << int(lg)
+            chips.append(dict(chip_id=int(cid), log_n=int(lg), main=w[at:at + int(mw) * h].reshape(int(mw), h)))
+            at += int(mw) * h
+        return chips, pubs
+
+    def job_free(self, job):
+        self.lib.dvt_job_free(self.h, job)
 
     def stage_ms(self):
         out = (C.c_float * 6)()

@@ -152,14 +152,23 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, Sink 
         s.put(U + 8, msb_b); s.put(U + 9, msb_c);
         s.byte(B_LTU - 1, (bc << 8) | ccv);
     } else if (F(F_MUL) | F(F_MULHU)) {
-        uint32_t acc = 0;
+        // (carries are materialised before any lookup is issued: with the atomics interleaved into
+        //  the carry chain hipcc 7.2 fed the k = 1 lookup an unshifted accumulator on gfx950 —
+        //  caught by tests/test_gpu_k0_parity.py)
+        uint32_t pbyte[8], pcarry[8], acc = 0;
         for (int k = 0; k < 8; k++) {
-            for (int i = 0; i < 4; i++) { int j = k - i; if (j >= 0 && j < 4) acc += B(b, i) * B(c, j); }
-            s.put(U + k, acc & 0xff);
-            s.put(U + 8 + k, acc >> 8);
-            s.byte(B_U16 - 1, acc >> 8);
-            acc >>= 8;
+            uint32_t t = acc;
+            for (int i = 0; i < 4; i++) { int j = k - i; if (j >= 0 && j < 4) t += B(b, i) * B(c, j); }
+            s.fence(t);  // keep the compiler from re-associating the carry chain across iterations
+            pbyte[k] = t & 0xff;
+            pcarry[k] = t >> 8;
+            acc = t >> 8;
         }
+        for (int k = 0; k < 8; k++) {
+            s.put(U + k, pbyte[k]);
+            s.put(U + 8 + k, pcarry[k]);
+        }
+        for (int k = 0; k < 8; k++) s.byte(B_U16 - 1, pcarry[k]);
         uint64_t pr = (uint64_t)b * c;
         for (int k = 0; k < 4; k++) s.byte(B_RANGE - 1, (((uint32_t)(pr >> (16 * k)) & 0xff) << 8) | ((uint32_t)(pr >> (16 * k + 8)) & 0xff));
     } else if (F(F_LW) | F(F_SW) | F(F_JALR)) {
@@ -209,6 +218,17 @@ struct HostPrep {
 };
 void build_prep(const Program &prog, HostPrep *out);
 bool build_traces_host(const Program &prog, const ExecResult &res, const HostPrep &prep, HostTraces *out, std::string *err);
+// Everything of a shard except the cpu trace and the lookups the cpu rows make: mem_init rows, the
+// byte-table multiplicities caused by mem_init, zeroed program/mem_image columns, public values.
+// The device path (K0) adds the cpu chip and its lookup counts on top.
+bool build_aux_host(const Program &prog, const ExecResult &res, const HostPrep &prep, HostTraces *out, std::string *err);
+// instruction index -> row of the program table (provable instructions only; others map to row 0 and never occur)
+std::vector<uint32_t> program_row_map(const Program &prog);
+
+#if defined(__HIPCC__)
+hipError_t launch_k0_cpu_rows(hipStream_t st, const CycleRec *d_recs, size_t n_recs, const Instr *d_instrs, const uint32_t *d_prog_row,
+                              uint32_t *d_cpu, uint32_t log_n, uint32_t *d_byte_mult, uint32_t *d_prog_mult);
+#endif
 
 }  // namespace rv32
 }  // namespace dvt

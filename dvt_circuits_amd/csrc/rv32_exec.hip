@@ -361,6 +361,7 @@ struct HostSink {
     void put(int col, uint32_t v) { cpu[(size_t)col * n + row] = v; }
     void byte(int op, uint32_t table_row) { byte_mult[(size_t)op * 65536 + table_row]++; }
     void prog(uint32_t idx) { prog_mult[idx]++; }
+    void fence(uint32_t &) {}
 };
 }  // namespace
 
@@ -371,14 +372,39 @@ bool build_traces_host(const Program &prog, const ExecResult &res, const HostPre
     const uint32_t lc = ceil_log2(res.recs.size());
     if (lc > 22) { if (err) *err = "shard too long (> 2^22 cycles); multi-shard proving lands next"; return false; }
     const size_t nc = (size_t)1 << lc;
-    T.log_n[RV32_CHIP_CPU] = lc;
+    if (!build_aux_host(prog, res, prep, out, err)) return false;
     T.main[RV32_CHIP_CPU].assign((size_t)RV32_CPU_MAIN_W * nc, 0);
-    std::vector<uint32_t> byte_mult((size_t)N_BYTE_OPS * 65536, 0), prog_idx_mult(prog.instrs.size(), 0);
-    HostSink sink{T.main[RV32_CHIP_CPU].data(), nc, 0, byte_mult.data(), prog_idx_mult.data()};
+    std::vector<uint32_t> prog_idx_mult(prog.instrs.size(), 0);
+    HostSink sink{T.main[RV32_CHIP_CPU].data(), nc, 0, T.main[RV32_CHIP_BYTE].data(), prog_idx_mult.data()};
     for (size_t r = 0; r < res.recs.size(); r++) {
         sink.row = r;
         fill_cpu_row(res.recs[r], prog.instrs[res.recs[r].idx], (uint32_t)r, sink);
     }
+    // program multiplicities follow the preprocessed row order (provable instructions only)
+    std::vector<uint32_t> rowmap = program_row_map(prog);
+    for (size_t i = 0; i < prog.instrs.size(); i++)
+        if (prog.instrs[i].supported) T.main[RV32_CHIP_PROGRAM][rowmap[i]] = prog_idx_mult[i];
+    return true;
+}
+
+std::vector<uint32_t> program_row_map(const Program &prog) {
+    std::vector<uint32_t> m(prog.instrs.size(), 0);
+    uint32_t r = 0;
+    for (size_t i = 0; i < prog.instrs.size(); i++)
+        if (prog.instrs[i].supported) m[i] = r++;
+    return m;
+}
+
+bool build_aux_host(const Program &prog, const ExecResult &res, const HostPrep &prep, HostTraces *out, std::string *err) {
+    HostTraces &T = *out;
+    if (res.recs.empty()) { if (err) *err = "no cycles to prove"; return false; }
+    if (res.unsupported) { if (err) *err = "unsupported " + res.unsupported_what; return false; }
+    const uint32_t lc = ceil_log2(res.recs.size());
+    if (lc > 22) { if (err) *err = "shard too long (> 2^22 cycles); multi-shard proving lands next"; return false; }
+    T.log_n[RV32_CHIP_CPU] = lc;
+    T.main[RV32_CHIP_CPU].clear();
+    std::vector<uint32_t> byte_mult((size_t)N_BYTE_OPS * 65536, 0);
+    HostSink sink{nullptr, 0, 0, byte_mult.data(), nullptr};
     // mem_init
     const uint32_t lm = ceil_log2(res.mem_rows.size());
     const size_t nm = (size_t)1 << lm;
@@ -405,15 +431,9 @@ bool build_traces_host(const Program &prog, const ExecResult &res, const HostPre
         }
         prev_addr = m.addr;
     }
-    // program multiplicities follow the preprocessed row order (provable instructions only)
     const uint32_t lp = prep.log_n[RV32_CHIP_PROGRAM];
     T.log_n[RV32_CHIP_PROGRAM] = lp;
     T.main[RV32_CHIP_PROGRAM].assign((size_t)1 << lp, 0);
-    {
-        size_t r = 0;
-        for (size_t i = 0; i < prog.instrs.size(); i++)
-            if (prog.instrs[i].supported) T.main[RV32_CHIP_PROGRAM][r++] = prog_idx_mult[i];
-    }
     T.log_n[RV32_CHIP_BYTE] = 16;
     T.main[RV32_CHIP_BYTE] = byte_mult;  // [7][65536] already column-major in op order
     T.log_n[RV32_CHIP_MEM_IMAGE] = prep.log_n[RV32_CHIP_MEM_IMAGE];

@@ -144,6 +144,18 @@ int dvt_execute(const uint8_t *elf, size_t elf_len, const dvt_buf *stdin_bufs, s
  * (src/main.rs:472-474) would write. */
 int dvt_prove_core(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_bufs, size_t nbuf, uint8_t **proof,
                    size_t *proof_len, dvt_report *report);
+/* The two halves of dvt_prove_core, split so that callers (and bench.py) can keep a
+ * shard resident in HBM: prepare = host execution + upload of the compact per-cycle
+ * records and the small auxiliary traces; prove_job = K0 (trace expansion) .. K9 on
+ * the GPU.  proof may be NULL to discard the bytes.  A job can be proven repeatedly. */
+typedef struct dvt_job dvt_job;
+int dvt_rv32_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_bufs, size_t nbuf, dvt_job **job,
+                     dvt_report *report);
+int dvt_rv32_prove_job(dvt_prover *p, const dvt_pk *pk, dvt_job *job, uint8_t **proof, size_t *proof_len);
+void dvt_job_free(dvt_prover *p, dvt_job *job);
+/* test hook: run K0 on a prepared job and return the device-generated main traces
+ * (canonical); blob layout as dvt_rv32_debug_traces with prep_width = 0. */
+int dvt_rv32_debug_device_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *job, uint32_t **blob, size_t *blob_words);
 /* stock `client.verify(&proof,&vk)` semantics (NOT the reference's re-execution
  * `verify` sub-command).  Host-only. */
 int dvt_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, size_t proof_len, uint32_t fri_queries,
