@@ -114,6 +114,10 @@ bool Engine::commit_tree(const std::vector<DevMat> &mats, uint32_t *d_digests) {
     uint32_t mx = 0;
     for (auto &m : mats) mx = std::max(mx, m.log_h);
     uint32_t *prev = nullptr;
+    MerkleTopInject inj;
+    bool in_top = false;
+    uint32_t top_start = 0;
+    uint32_t *top_layer = nullptr;
     for (uint32_t lh = mx + 1; lh-- > 0;) {
         std::vector<uint64_t> ptrs;
         for (auto &m : mats)
@@ -127,22 +131,31 @@ bool Engine::commit_tree(const std::vector<DevMat> &mats, uint32_t *d_digests) {
         if (lh == mx) {
             HIPCHK(launch_merkle_leaves(stream, d_cols, (uint32_t)ptrs.size(), lh, d_digests));
             prev = d_digests;
+            if (lh <= MERKLE_TOP_LOG) { in_top = true; top_start = lh; top_layer = prev; }
+        } else if (in_top) {
+            inj.cols[lh] = d_cols;
+            inj.ncols[lh] = (uint32_t)ptrs.size();
         } else {
             uint32_t *cur = prev + ((size_t)16 << lh);
             HIPCHK(launch_merkle_level(stream, prev, d_cols, (uint32_t)ptrs.size(), lh, cur));
             prev = cur;
+            if (lh <= MERKLE_TOP_LOG) { in_top = true; top_start = lh; top_layer = prev; }
         }
     }
+    if (in_top) HIPCHK(launch_merkle_top(stream, top_layer, top_start, inj));
     return true;
 }
 
 bool Engine::commit_tree_levels(uint32_t *d_digests, uint32_t log_h) {
     uint32_t *prev = d_digests;
-    for (uint32_t lh = log_h; lh-- > 0;) {
+    uint32_t lh = log_h;
+    while (lh > MERKLE_TOP_LOG) {
+        lh--;
         uint32_t *cur = prev + ((size_t)16 << lh);
         HIPCHK(launch_merkle_level(stream, prev, nullptr, 0, lh, cur));
         prev = cur;
     }
+    HIPCHK(launch_merkle_top(stream, prev, lh, MerkleTopInject()));
     return true;
 }
 

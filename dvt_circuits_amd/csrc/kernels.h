@@ -37,6 +37,13 @@ hipError_t launch_merkle_leaves(hipStream_t st, const uint32_t *const *d_cols, u
 // d_out[i] = compress(d_out[i], sponge(row i of the injected columns))
 hipError_t launch_merkle_level(hipStream_t st, const uint32_t *d_prev, const uint32_t *const *d_cols, uint32_t ncols,
                                uint32_t log_len, uint32_t *d_out);
+// every level below a layer of 2^log_start <= 2^MERKLE_TOP_LOG nodes, down to the root, in one launch
+constexpr uint32_t MERKLE_TOP_LOG = 11;
+struct MerkleTopInject {  // per level lh (nodes = 2^lh): columns injected at that level
+    const uint32_t *const *cols[MERKLE_TOP_LOG + 1] = {};
+    uint32_t ncols[MERKLE_TOP_LOG + 1] = {};
+};
+hipError_t launch_merkle_top(hipStream_t st, uint32_t *d_layer, uint32_t log_start, const MerkleTopInject &inj);
 hipError_t launch_poseidon2_permute(hipStream_t st, uint32_t *d_states, size_t n);
 
 // fri.hip

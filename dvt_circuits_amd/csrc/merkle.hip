@@ -73,6 +73,46 @@ __global__ void __launch_bounds__(256) merkle_level_kernel(const uint32_t *prev,
     store_digest(out, i, s);
 }
 
+// All levels from a layer of 2^log_start nodes (log_start <= MERKLE_TOP_LOG) down to the root in ONE
+// single-workgroup launch: the upper levels are launch-latency bound (a proof has ~25 trees x ~11 of
+// them), so they share a launch and synchronise with __syncthreads().  Every node is written once and
+// read once afterwards by the same workgroup, so no cross-CU visibility is involved.
+__global__ void __launch_bounds__(1024) merkle_top_kernel(uint32_t *layer, uint32_t log_start, MerkleTopInject inj) {
+    uint32_t *prev = layer;
+    for (uint32_t lh = log_start; lh-- > 0;) {
+        const size_t len = (size_t)1 << lh;
+        uint32_t *cur = prev + ((size_t)16 << lh);
+        for (size_t i = threadIdx.x; i < len; i += blockDim.x) {
+            const uint4 *pl = reinterpret_cast<const uint4 *>(prev + i * 8);
+            const uint4 *pr = reinterpret_cast<const uint4 *>(prev + (i + len) * 8);
+            uint4 a = pl[0], b = pl[1], c = pr[0], d = pr[1];
+            Fp s[16] = {Fp::raw(a.x), Fp::raw(a.y), Fp::raw(a.z), Fp::raw(a.w), Fp::raw(b.x), Fp::raw(b.y),
+                        Fp::raw(b.z), Fp::raw(b.w), Fp::raw(c.x), Fp::raw(c.y), Fp::raw(c.z), Fp::raw(c.w),
+                        Fp::raw(d.x), Fp::raw(d.y), Fp::raw(d.z), Fp::raw(d.w)};
+            p2_permute(s);
+            if (inj.ncols[lh]) {
+                Fp h[16];
+                hash_row(inj.cols[lh], inj.ncols[lh], i, h);
+#pragma unroll
+                for (int k = 0; k < 8; k++) s[8 + k] = h[k];
+                p2_permute(s);
+            }
+            store_digest(cur, i, s);
+        }
+        __threadfence_block();
+        __syncthreads();
+        prev = cur;
+    }
+}
+
+hipError_t launch_merkle_top(hipStream_t st, uint32_t *d_layer, uint32_t log_start, const MerkleTopInject &inj) {
+    if (log_start == 0) return hipSuccess;
+    if (log_start > MERKLE_TOP_LOG) return hipErrorInvalidValue;
+    unsigned threads = log_start >= 11 ? 1024 : (log_start <= 6 ? 64 : 1u << (log_start - 1));
+    merkle_top_kernel<<<1, threads, 0, st>>>(d_layer, log_start, inj);
+    return hipGetLastError();
+}
+
 __global__ void poseidon2_permute_kernel(uint32_t *states, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

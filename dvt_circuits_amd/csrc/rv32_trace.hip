@@ -2,51 +2,90 @@
 //
 // The host executor uploads one compact 48-byte record per retired instruction;
 // one thread expands one record into the 86 columns of the cpu chip (byte limbs,
-// carries, comparator flags, product bytes, ...) and counts its table lookups with
-// integer atomics on the byte-table and program-table multiplicity columns.
+// carries, comparator flags, product bytes, ...) and counts its table lookups in
+// the byte-table and program-table multiplicity columns.
 // Column-major output: the 64 lanes of a wave write 64 consecutive rows of a
 // column, so every store is a coalesced 256-B request.  HBM-write bound
 // (4 B x 86 columns per cycle against 48 B read).
+//
+// Lookup counting: a few table rows are extremely hot (the high limbs of the
+// timestamp differences are almost always (0,0); loop bodies hit the same dozen
+// program rows), and plain global atomics on them serialise at the memory side
+// (50 ms per 2^21-row shard).  So every workgroup keeps a direct-mapped LDS cache
+// of (key -> count): hits are LDS atomics, conflicts fall through to a global
+// atomic, and the cache is flushed once per workgroup.  A wave whose active lanes
+// all carry the same key adds its lane count with a single LDS atomic.
 #include "kernels.h"
 #include "rv32.h"
 
 namespace dvt {
 namespace rv32 {
 
+constexpr uint32_t K0_SLOTS = 4096;            // 32 KiB of LDS per workgroup
+constexpr uint32_t K0_ROWS_PER_BLOCK = 2048;   // rows expanded by one workgroup (8 per thread)
+constexpr uint32_t K0_EMPTY = 0xffffffffu;
+constexpr uint32_t K0_PROG_KEY_BASE = N_BYTE_OPS * 65536;  // program-table keys follow the byte-table keys
+
 struct DeviceSink {
     uint32_t *cpu;
     size_t n, row;
     uint32_t *byte_mult, *prog_mult;
     const uint32_t *prog_row;
+    uint32_t *lds_keys, *lds_counts;
+
     __device__ void put(int col, uint32_t v) { cpu[(size_t)col * n + row] = Fp::from_canonical(v).v; }
-    __device__ void byte(int op, uint32_t table_row) {
-        // Materialise the row index in a VGPR before it enters the address computation: with the
-        // carry chain of the MUL family folded into the atomic's address arithmetic, hipcc 7.2 (gfx950)
-        // produced ((t0 + terms1) >> 8) instead of (((t0 >> 8) + terms1) >> 8) for the k = 1 lookup
-        // (tests/test_gpu_k0_parity.py caught it; the stored columns were correct).
-        asm volatile("" : "+v"(table_row));
-        atomicAdd(&byte_mult[(size_t)op * 65536 + table_row], 1u);
-    }
+    // (see rv32.h: keeps hipcc from re-associating the MUL carry chain)
     __device__ void fence(uint32_t &v) { asm volatile("" : "+v"(v)); }
-    __device__ void prog(uint32_t idx) { atomicAdd(&prog_mult[prog_row[idx]], 1u); }
+
+    __device__ void global_add(uint32_t key, uint32_t cnt) {
+        if (key < K0_PROG_KEY_BASE) atomicAdd(&byte_mult[key], cnt);
+        else atomicAdd(&prog_mult[key - K0_PROG_KEY_BASE], cnt);
+    }
+    __device__ void count(uint32_t key) {
+        // wave-uniform fast path: every active lane has the same key -> one add of the lane count
+        const uint32_t first = __builtin_amdgcn_readfirstlane(key);
+        const unsigned long long active = __ballot(1), same = __ballot(key == first);
+        uint32_t cnt = 1;
+        if (same == active) {
+            if (__builtin_amdgcn_mbcnt_hi((uint32_t)(active >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)active, 0)) != 0) return;
+            cnt = (uint32_t)__popcll(active);
+        }
+        const uint32_t slot = (key * 2654435761u) >> 20;  // 12 bits
+        const uint32_t old = atomicCAS(&lds_keys[slot], K0_EMPTY, key);
+        if (old == K0_EMPTY || old == key) atomicAdd(&lds_counts[slot], cnt);
+        else global_add(key, cnt);
+    }
+    __device__ void byte(int op, uint32_t table_row) { count((uint32_t)op * 65536u + table_row); }
+    __device__ void prog(uint32_t idx) { count(K0_PROG_KEY_BASE + prog_row[idx]); }
 };
 
 __global__ void __launch_bounds__(256) k0_cpu_rows_kernel(const CycleRec *recs, size_t n_recs, const Instr *instrs, const uint32_t *prog_row,
                                                          uint32_t *cpu, uint32_t log_n, uint32_t *byte_mult, uint32_t *prog_mult) {
-    size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_recs) return;
-    const CycleRec rec = recs[r];
-    const Instr in = instrs[rec.idx];
-    DeviceSink s{cpu, (size_t)1 << log_n, r, byte_mult, prog_mult, prog_row};
-    fill_cpu_row(rec, in, (uint32_t)r, s);
+    __shared__ uint32_t keys[K0_SLOTS], counts[K0_SLOTS];
+    for (uint32_t s = threadIdx.x; s < K0_SLOTS; s += blockDim.x) { keys[s] = K0_EMPTY; counts[s] = 0; }
+    __syncthreads();
+    DeviceSink sink{cpu, (size_t)1 << log_n, 0, byte_mult, prog_mult, prog_row, keys, counts};
+    const size_t base = (size_t)blockIdx.x * K0_ROWS_PER_BLOCK;
+    for (uint32_t k = 0; k < K0_ROWS_PER_BLOCK / 256; k++) {
+        size_t r = base + (size_t)k * 256 + threadIdx.x;
+        if (r < n_recs) {
+            const CycleRec rec = recs[r];
+            const Instr in = instrs[rec.idx];
+            sink.row = r;
+            fill_cpu_row(rec, in, (uint32_t)r, sink);
+        }
+    }
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < K0_SLOTS; s += blockDim.x)
+        if (keys[s] != K0_EMPTY && counts[s]) sink.global_add(keys[s], counts[s]);
 }
 
 hipError_t launch_k0_cpu_rows(hipStream_t st, const CycleRec *d_recs, size_t n_recs, const Instr *d_instrs, const uint32_t *d_prog_row,
                               uint32_t *d_cpu, uint32_t log_n, uint32_t *d_byte_mult, uint32_t *d_prog_mult) {
     hipError_t e = hipMemsetAsync(d_cpu, 0, ((size_t)RV32_CPU_MAIN_W << log_n) * 4, st);
     if (e != hipSuccess) return e;
-    k0_cpu_rows_kernel<<<(unsigned)((n_recs + 255) / 256), 256, 0, st>>>(d_recs, n_recs, d_instrs, d_prog_row, d_cpu, log_n, d_byte_mult,
-                                                                         d_prog_mult);
+    unsigned blocks = (unsigned)((n_recs + K0_ROWS_PER_BLOCK - 1) / K0_ROWS_PER_BLOCK);
+    k0_cpu_rows_kernel<<<blocks, 256, 0, st>>>(d_recs, n_recs, d_instrs, d_prog_row, d_cpu, log_n, d_byte_mult, d_prog_mult);
     return hipGetLastError();
 }
 
