@@ -60,6 +60,16 @@ void orc_perm_trace(const orc_chip_air *chip, const uint32_t *main, const uint32
                     const uint32_t *pub, const uint32_t alpha[4], const uint32_t beta[4], uint32_t *perm_out,
                     uint32_t cumsum_out[4]);
 
+/* K5..K8 restatements (stark_oracle.c).  All arrays canonical; extension elements are 4 words. */
+void orc_quotient(const orc_chip_air *chip, const uint32_t *main_lde, const uint32_t *prep_lde, const uint32_t *perm_lde,
+                  uint32_t log_n, const uint32_t *pub, const uint32_t perm_alpha[4], const uint32_t beta[4],
+                  const uint32_t alpha[4], const uint32_t cumsum[4], uint32_t *out);
+void orc_eval_columns(const uint32_t *cols, uint32_t width, uint32_t log_n, uint32_t coset_shift, const uint32_t z[4], uint32_t *out);
+void orc_reduced_opening(const uint32_t *const *cols, uint32_t n_two, uint32_t n_all, uint32_t log_m, const uint32_t alpha[4],
+                         const uint32_t *open_local, const uint32_t *open_next, const uint32_t zeta[4], const uint32_t zeta_next[4],
+                         uint32_t *out);
+void orc_fri_fold(const uint32_t *v, uint32_t log_m, const uint32_t beta[4], const uint32_t *ro, uint32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

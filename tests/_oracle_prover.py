@@ -1,0 +1,296 @@
+"""TEST INFRASTRUCTURE: a complete CPU shard prover assembled from the oracle's stage
+restatements (oracle/*.c through ctypes) and a Python duplex challenger.  It follows
+DESIGN.md "Protocol" step by step and serialises with the wire format of DESIGN.md
+"Proof format"; tests require its bytes to equal the GPU prover's.  Slow by design —
+use it on small shards."""
+import ctypes as C
+
+import numpy as np
+
+from tests import _orc
+
+P = 2013265921
+G = 31
+u32p = _orc.u32p
+
+
+# ---------------------------------------------------------------- field helpers (python ints)
+def ef_mul(a, b):
+    t = [0] * 7
+    for i in range(4):
+        for j in range(4):
+            t[i + j] += a[i] * b[j]
+    return [(t[i] + 11 * (t[i + 4] if i + 4 < 7 else 0)) % P for i in range(4)]
+
+
+def ef_scale(a, s):
+    return [x * s % P for x in a]
+
+
+def two_adic(k):
+    return pow(G, (P - 1) >> k, P)
+
+
+class Challenger:
+    def __init__(self, orc):
+        self.orc, self.state, self.inp, self.out = orc, [0] * 16, [], []
+
+    def duplex(self):
+        self.state[: len(self.inp)] = self.inp
+        self.inp = []
+        self.state = self.orc.permute(np.array(self.state, np.uint32)).tolist()
+        self.out = self.state[:8]
+
+    def observe(self, xs):
+        for x in np.atleast_1d(xs).tolist():
+            self.out = []
+            self.inp.append(int(x) % P)
+            if len(self.inp) == 8:
+                self.duplex()
+
+    def sample(self):
+        if self.inp or not self.out:
+            self.duplex()
+        return self.out.pop()
+
+    def sample_ext(self):
+        return [self.sample() for _ in range(4)]
+
+    def sample_bits(self, bits):
+        return self.sample() & ((1 << bits) - 1)
+
+
+def _lib(orc):
+    lib = orc.lib
+    lib.orc_quotient.argtypes = [C.c_void_p, u32p, u32p, u32p, C.c_uint32, u32p, u32p, u32p, u32p, u32p, u32p]
+    lib.orc_eval_columns.argtypes = [u32p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]
+    lib.orc_reduced_opening.argtypes = [C.POINTER(u32p), C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p, u32p, u32p, u32p, u32p]
+    lib.orc_fri_fold.argtypes = [u32p, C.c_uint32, u32p, u32p, u32p]
+    return lib
+
+
+def _a(x):
+    x = np.ascontiguousarray(x, dtype=np.uint32)
+    return x if x.size else np.zeros(1, np.uint32)
+
+
+def _p(x):
+    return x.ctypes.data_as(u32p)
+
+
+def tree_path(layers, log_h, idx):
+    out = []
+    for s in range(log_h, 0, -1):
+        off = (2 << log_h) - (2 << s)
+        j = idx & ((1 << s) - 1)
+        out.append(layers[off + (j ^ (1 << (s - 1)))])
+    return out
+
+
+class Writer:
+    def __init__(self):
+        self.w = []
+
+    def u32(self, v):
+        self.w.append(int(v))
+
+    def ef(self, v):
+        self.w += [int(x) for x in v]
+
+    def dg(self, d):
+        self.w += [int(x) for x in d]
+
+    def efs(self, vs):
+        self.u32(len(vs))
+        for v in vs:
+            self.ef(v)
+
+    def dgs(self, ds):
+        self.u32(len(ds))
+        for d in ds:
+            self.dg(d)
+
+    def fps(self, v):
+        self.u32(len(v))
+        self.w += [int(x) for x in v]
+
+    def bytes(self):
+        return np.array(self.w, dtype=np.uint32).tobytes()
+
+
+def prove_shard(machine, chips, pubs, num_queries, pow_bits):
+    """chips: list of dict(chip_id, main [w][N], prep [w][N]) sorted by chip id (every chip of the shard).
+    Returns the shard proof bytes and the preprocessed root (8 ints)."""
+    orc = _orc.load()
+    air = _orc.air(machine)
+    lib = _lib(orc)
+    npub = len(pubs)
+    pubs = _a(pubs)
+    cs = []
+    for ch in chips:
+        d = air.chip(ch["chip_id"])
+        n = ch["main"].shape[1]
+        cs.append(dict(id=ch["chip_id"], d=d, log_n=int(n).bit_length() - 1, n=n, main=_a(ch["main"]),
+                       prep=_a(ch["prep"]) if d.prep_w else None, ext_w=((d.n_interactions + 1) // 2 + 1) if d.n_interactions else 0))
+    hmax = max(c["log_n"] for c in cs) + 1
+
+    def commit(mats):
+        layers = orc.merkle_commit(mats)
+        return layers, layers[-1].tolist()
+
+    # preprocessed tree (what setup commits)
+    prep_mats = [(c, orc.coset_lde(c["prep"], 1, G)) for c in cs if c["prep"] is not None]
+    for c, l in prep_mats:
+        c["prep_lde"] = l
+    prep_layers, prep_root = commit([l for _, l in prep_mats]) if prep_mats else (None, [0] * 8)
+    prep_log_h = max([c["log_n"] + 1 for c, _ in prep_mats], default=0)
+
+    ch = Challenger(orc)
+    ch.observe(prep_root)
+    ch.observe([len(cs)])
+    for c in cs:
+        ch.observe([c["id"], c["log_n"]])
+    # 1. main
+    for c in cs:
+        c["main_lde"] = orc.coset_lde(c["main"], 1, G)
+    main_layers, main_root = commit([c["main_lde"] for c in cs])
+    ch.observe(main_root)
+    ch.observe([npub])
+    ch.observe(pubs[:npub])
+    # 2. permutation
+    perm_alpha, beta = ch.sample_ext(), ch.sample_ext()
+    perm_cs = [c for c in cs if c["ext_w"]]
+    for c in cs:
+        c["cumsum"] = [0, 0, 0, 0]
+        c["perm"] = None
+    for c in perm_cs:
+        perm, cum = air.perm_trace(c["id"], c["main"], c["prep"] if c["prep"] is not None else np.zeros((1, c["n"]), np.uint32), pubs, perm_alpha, beta)
+        c["perm"], c["cumsum"] = perm, cum.tolist()
+        c["perm_lde"] = orc.coset_lde(perm, 1, G)
+    perm_layers, perm_root = commit([c["perm_lde"] for c in perm_cs]) if perm_cs else (None, [0] * 8)
+    perm_log_h = max([c["log_n"] + 1 for c in perm_cs], default=0)
+    ch.observe(perm_root)
+    for c in cs:
+        ch.observe(c["cumsum"])
+    # 3. quotient
+    alpha = ch.sample_ext()
+    for c in cs:
+        n = c["n"]
+        out = np.zeros((8, n), np.uint32)
+        z = np.zeros(1, np.uint32)
+        lib.orc_quotient(C.addressof(air.chips[c["id"]]), _p(c["main_lde"]), _p(c["prep_lde"]) if c["prep"] is not None else _p(z),
+                         _p(c["perm_lde"]) if c["ext_w"] else _p(z), c["log_n"], _p(pubs), _p(_a(perm_alpha)), _p(_a(beta)),
+                         _p(_a(alpha)), _p(_a(c["cumsum"])), _p(out))
+        c["quot"] = out
+        w2inv = pow(two_adic(c["log_n"] + 1), P - 2, P)
+        c["quot_lde"] = np.concatenate([orc.coset_lde(out[:4], 1, 1), orc.coset_lde(out[4:], 1, w2inv)])
+    quot_layers, quot_root = commit([c["quot_lde"] for c in cs])
+    ch.observe(quot_root)
+    # 4. openings
+    zeta = ch.sample_ext()
+
+    def evals(cols, log_n, shift, z):
+        cols = _a(cols)
+        out = np.zeros((cols.shape[0], 4), np.uint32)
+        lib.orc_eval_columns(_p(cols), cols.shape[0], log_n, shift, _p(_a(z)), _p(out))
+        return out.tolist()
+
+    for c in cs:
+        zn = ef_scale(zeta, two_adic(c["log_n"]))
+        c["open"] = {}
+        for name, m in (("prep", c["prep"]), ("main", c["main"]), ("perm", c["perm"])):
+            c["open"][name + "_l"] = evals(m, c["log_n"], 1, zeta) if m is not None else []
+            c["open"][name + "_n"] = evals(m, c["log_n"], 1, zn) if m is not None else []
+        s1 = G * two_adic(c["log_n"] + 1) % P
+        c["open"]["quot"] = evals(c["quot"][:4], c["log_n"], G, zeta) + evals(c["quot"][4:], c["log_n"], s1, zeta)
+    for c in cs:
+        for k in ("prep_l", "prep_n", "main_l", "main_n", "perm_l", "perm_n", "quot"):
+            for v in c["open"][k]:
+                ch.observe(v)
+    # 5. FRI input
+    alpha_fri = ch.sample_ext()
+    ro = {}
+    for h in range(1, hmax + 1):
+        two, one = [], []  # (lde column, open_local, open_next)
+        for key, okey in (("prep_lde", "prep"), ("main_lde", "main"), ("perm_lde", "perm")):
+            for c in cs:
+                if c["log_n"] + 1 == h and c.get(key) is not None and (okey != "perm" or c["ext_w"]) and (okey != "prep" or c["prep"] is not None):
+                    for col in range(c[key].shape[0]):
+                        two.append((c[key][col], c["open"][okey + "_l"][col], c["open"][okey + "_n"][col]))
+        for c in cs:
+            if c["log_n"] + 1 == h:
+                for col in range(8):
+                    one.append((c["quot_lde"][col], c["open"]["quot"][col], None))
+        allc = two + one
+        if not allc:
+            continue
+        keep = [np.ascontiguousarray(x[0]) for x in allc]
+        ptrs = (u32p * len(allc))(*[_p(k) for k in keep])
+        ol = _a([x[1] for x in allc])
+        on = _a([x[2] for x in two]) if two else np.zeros(4, np.uint32)
+        out = np.zeros((1 << h, 4), np.uint32)
+        zn = ef_scale(zeta, two_adic(h - 1))
+        lib.orc_reduced_opening(ptrs, len(two), len(allc), h, _p(_a(alpha_fri)), _p(ol), _p(on), _p(_a(zeta)), _p(_a(zn)), _p(out))
+        ro[h] = out
+    # 6. FRI commit phase
+    cur = ro[hmax]
+    fri_layers, fri_roots, fri_vecs = [], [], []
+    for lm in range(hmax, 1, -1):
+        half = 1 << (lm - 1)
+        mat = np.ascontiguousarray(np.concatenate([cur[:half].T, cur[half:].T]))  # [8][half]
+        layers, root = commit([mat])
+        fri_layers.append(layers)
+        fri_vecs.append(cur)
+        fri_roots.append(root)
+        ch.observe(root)
+        fb = ch.sample_ext()
+        nxt = np.zeros((half, 4), np.uint32)
+        r = ro.get(lm - 1)
+        lib.orc_fri_fold(_p(np.ascontiguousarray(cur)), lm, _p(_a(fb)), _p(np.ascontiguousarray(r)) if r is not None else None, _p(nxt))
+        cur = nxt
+    assert cur.shape[0] == 2 and (cur[0] == cur[1]).all(), "oracle: FRI final polynomial is not constant"
+    final_poly = cur[0].tolist()
+    ch.observe(final_poly)
+    # 7. proof of work: smallest witness
+    base = list(ch.state)
+    base[: len(ch.inp)] = ch.inp
+    pos, mask, w = len(ch.inp), (1 << pow_bits) - 1, 0
+    while True:
+        s = list(base)
+        s[pos] = w
+        if orc.permute(np.array(s, np.uint32))[7] & mask == 0:
+            break
+        w += 1
+    ch.observe([w])
+    assert ch.sample_bits(pow_bits) == 0
+    idx = [ch.sample_bits(hmax) for _ in range(num_queries)]
+    # 8. serialise
+    W = Writer()
+    W.u32(0x31505644)
+    W.dg(main_root); W.dg(perm_root); W.dg(quot_root)
+    W.fps(pubs[:npub].tolist())
+    W.u32(len(cs))
+    for c in cs:
+        W.u32(c["id"]); W.u32(c["log_n"]); W.ef(c["cumsum"])
+        for k in ("prep_l", "prep_n", "main_l", "main_n", "perm_l", "perm_n", "quot"):
+            W.efs(c["open"][k])
+    W.dgs(fri_roots); W.ef(final_poly); W.u32(w)
+    W.u32(num_queries)
+    trees = [
+        ([c["prep_lde"] for c in cs if c["prep"] is not None], prep_layers, prep_log_h),
+        ([c["main_lde"] for c in cs], main_layers, hmax),
+        ([c["perm_lde"] for c in perm_cs], perm_layers, perm_log_h),
+        ([c["quot_lde"] for c in cs], quot_layers, hmax),
+    ]
+    for q in idx:
+        for mats, layers, log_h in trees:
+            W.u32(len(mats))
+            for m in mats:
+                W.fps(m[:, q & (m.shape[1] - 1)].tolist())
+            W.dgs(tree_path(layers, log_h, q) if mats else [])
+        W.u32(len(fri_layers))
+        for k, lm in enumerate(range(hmax, 1, -1)):
+            j = q & ((1 << lm) - 1)
+            W.ef(fri_vecs[k][j ^ (1 << (lm - 1))].tolist())
+            W.dgs(tree_path(fri_layers[k], lm - 1, q))
+    return W.bytes(), prep_root
