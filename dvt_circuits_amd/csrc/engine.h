@@ -74,8 +74,14 @@ struct ProvingKey {
     uint32_t prep_log_h = 0;  // log2 of the tallest preprocessed LDE
 };
 
-struct StageTimes {  // milliseconds, HIP events on the prover stream
+struct StageTimes {  // milliseconds, HIP events on the prover stream (profile mode)
     float commit_main = 0, perm = 0, quotient = 0, open = 0, fri = 0, total = 0;
+    // kernel families, summed over the launches of one prove_shard call
+    float lde_ms = 0;          // K1: ntt_strided<inverse> + lde_block + ntt_strided<forward>
+    double lde_alg_bytes = 0;  // sum over LDE calls of 12 * width * N  (read N words, write 2N words per column)
+    int lde_calls = 0;
+    float merkle_ms = 0;       // K2 + K3 of the three trace commitments (leaf hashing + levels)
+    double merkle_perms = 0;   // Poseidon2 permutations executed by them
 };
 
 class Engine {

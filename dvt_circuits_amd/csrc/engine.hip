@@ -267,6 +267,32 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
     arena.reset();
     times = StageTimes();
     EventTimer tm(stream, profile), tm_total(stream, profile);
+    // per-family timing (profile mode only: the extra event synchronisations serialise the stream)
+    auto lde = [&](uint32_t *in, uint32_t *scratch, uint32_t *outp, uint32_t width, uint32_t log_n, uint32_t mode) -> hipError_t {
+        if (!profile) return launch_coset_lde(stream, tabs, in, scratch, outp, width, log_n, mode);
+        EventTimer t(stream, true);
+        hipError_t e = launch_coset_lde(stream, tabs, in, scratch, outp, width, log_n, mode);
+        times.lde_ms += t.stop();
+        times.lde_alg_bytes += 12.0 * width * (double)((size_t)1 << log_n);
+        times.lde_calls++;
+        return e;
+    };
+    auto commit = [&](const std::vector<DevMat> &ms, uint32_t *d_digests) -> bool {
+        if (!profile) return commit_tree(ms, d_digests);
+        EventTimer t(stream, true);
+        bool ok = commit_tree(ms, d_digests);
+        times.merkle_ms += t.stop();
+        uint32_t mxh = 0;
+        for (auto &mm : ms) mxh = std::max(mxh, mm.log_h);
+        for (uint32_t lh = 0; lh <= mxh; lh++) {
+            uint32_t w = 0;
+            for (auto &mm : ms) if (mm.log_h == lh) w += mm.width;
+            double rows = (double)((size_t)1 << lh);
+            if (lh == mxh) times.merkle_perms += rows * ((w + 7) / 8);
+            else times.merkle_perms += rows * (1 + (w ? 1 + (w + 7) / 8 : 0));
+        }
+        return ok;
+    };
 
     // ---- validate inputs and lay out per-chip state
     std::vector<ChipState> cs;
@@ -338,12 +364,12 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
     std::vector<DevMat> mats;
     for (auto &s : cs) {
         ALLOC(s.main_lde, uint32_t, (size_t)s.d->main_w * 2 * s.n);
-        HIPCHK(launch_coset_lde(stream, tabs, const_cast<uint32_t *>(s.main), d_scratch, s.main_lde, s.d->main_w, s.log_n, 0));
+        HIPCHK(lde(const_cast<uint32_t *>(s.main), d_scratch, s.main_lde, s.d->main_w, s.log_n, 0));
         mats.push_back({s.main_lde, (uint32_t)s.d->main_w, s.log_n + 1});
     }
     uint32_t *d_main_tree;
     ALLOC(d_main_tree, uint32_t, tree_words(hmax));
-    if (!commit_tree(mats, d_main_tree)) return false;
+    if (!commit(mats, d_main_tree)) return false;
     uint32_t rootw[8];
     if (!download(rootw, tree_root(d_main_tree, hmax), 32)) return false;
     pf.main_root = digest_from_words(rootw);
@@ -380,7 +406,7 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
             HIPCHK(hipMemcpyAsync(&cw[k], phi + (size_t)k * s.n + s.n - 1, 4, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         for (int k = 0; k < 4; k++) s.cumsum.c[k] = Fp::raw(cw[k]);
-        HIPCHK(launch_coset_lde(stream, tabs, s.perm, d_scratch, s.perm_lde, (uint32_t)bw, s.log_n, 0));
+        HIPCHK(lde(s.perm, d_scratch, s.perm_lde, (uint32_t)bw, s.log_n, 0));
         mats.push_back({s.perm_lde, (uint32_t)bw, s.log_n + 1});
         perm_hmax = std::max(perm_hmax, s.log_n + 1);
     }
@@ -388,7 +414,7 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
     for (int i = 0; i < 8; i++) pf.perm_root.d[i] = Fp::zero();
     if (!mats.empty()) {
         ALLOC(d_perm_tree, uint32_t, tree_words(perm_hmax));
-        if (!commit_tree(mats, d_perm_tree)) return false;
+        if (!commit(mats, d_perm_tree)) return false;
         if (!download(rootw, tree_root(d_perm_tree, perm_hmax), 32)) return false;
         pf.perm_root = digest_from_words(rootw);
     }
@@ -418,13 +444,13 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
         qa.log_n = s.log_n;
         qa.tabs = tabs;
         HIPCHK(s.d->launch_quotient(stream, qa));
-        HIPCHK(launch_coset_lde(stream, tabs, s.quot, d_scratch, s.quot_lde, 4, s.log_n, 1));
-        HIPCHK(launch_coset_lde(stream, tabs, s.quot + 4 * s.n, d_scratch, s.quot_lde + 8 * s.n, 4, s.log_n, 2));
+        HIPCHK(lde(s.quot, d_scratch, s.quot_lde, 4, s.log_n, 1));
+        HIPCHK(lde(s.quot + 4 * s.n, d_scratch, s.quot_lde + 8 * s.n, 4, s.log_n, 2));
         mats.push_back({s.quot_lde, 8, s.log_n + 1});
     }
     uint32_t *d_quot_tree;
     ALLOC(d_quot_tree, uint32_t, tree_words(hmax));
-    if (!commit_tree(mats, d_quot_tree)) return false;
+    if (!commit(mats, d_quot_tree)) return false;
     if (!download(rootw, tree_root(d_quot_tree, hmax), 32)) return false;
     pf.quot_root = digest_from_words(rootw);
     ch.observe(pf.quot_root);

@@ -115,6 +115,11 @@ int dvt_machine_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, s
 /* per-stage milliseconds of the last dvt_machine_prove on this handle (needs "profile":1):
  * out[0..5] = commit_main, permutation, quotient, openings, fri, total */
 int dvt_last_stage_ms(dvt_prover *p, float out[6]);
+/* kernel-family totals of the last prove on this handle (needs "profile":1), measured with HIP
+ * events on the prover stream: out[0] = K1 LDE milliseconds, out[1] = K1 algorithmic bytes
+ * (12 B per input element: read N, write 2N words per column), out[2] = K1 calls,
+ * out[3] = K2+K3 (trace commitments) milliseconds, out[4] = Poseidon2 permutations they ran */
+int dvt_last_kernel_stats(dvt_prover *p, double out[5]);
 
 /* ------------------------------------------------- the reference's boundary
  * These five calls are what the reference's FFI for this path binds

@@ -134,11 +134,14 @@ void orc_perm_trace(const orc_chip_air *chip, const uint32_t *main, const uint32
     ef_t *bp = malloc(sizeof(ef_t) * (chip->max_arity + 1));
     bp[0] = be;
     for (uint32_t k = 1; k < chip->max_arity; k++) bp[k] = ef_mul(bp[k - 1], be);
+#pragma omp parallel
+    {
     uint32_t *ml = malloc(4 * (chip->main_w + 1)), *mn = malloc(4 * (chip->main_w + 1));
     uint32_t *pl = malloc(4 * (chip->prep_w + 1)), *pn = malloc(4 * (chip->prep_w + 1));
     uint32_t *mult = malloc(4 * (ni + 1)), *vals = malloc(4 * (size_t)(ni + 1) * chip->max_arity);
-    ef_t phi = ef_zero();
+#pragma omp for schedule(static)
     for (size_t r = 0; r < n; r++) {
+        ef_t phi = ef_zero();  /* row total; turned into the running sum below */
         size_t rn = (r + 1) & (n - 1);
         gather_row(main, chip->main_w, n, r, ml);
         gather_row(main, chip->main_w, n, rn, mn);
@@ -159,6 +162,15 @@ void orc_perm_trace(const orc_chip_air *chip, const uint32_t *main, const uint32
         }
         for (int k = 0; k < 4; k++) perm_out[(size_t)(4 * nb + k) * n + r] = phi.c[k];
     }
-    memcpy(cumsum_out, phi.c, 16);
-    free(bp); free(ml); free(mn); free(pl); free(pn); free(mult); free(vals);
+    free(ml); free(mn); free(pl); free(pn); free(mult); free(vals);
+    }
+    ef_t run = ef_zero();
+    for (size_t r = 0; r < n; r++) {
+        ef_t t;
+        for (int k = 0; k < 4; k++) t.c[k] = perm_out[(size_t)(4 * nb + k) * n + r];
+        run = ef_add(run, t);
+        for (int k = 0; k < 4; k++) perm_out[(size_t)(4 * nb + k) * n + r] = run.c[k];
+    }
+    memcpy(cumsum_out, run.c, 16);
+    free(bp);
 }

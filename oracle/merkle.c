@@ -37,11 +37,16 @@ void orc_merkle_commit(const orc_matrix *mats, size_t n, uint32_t *digests) {
         if (mats[m].log_height > mx) mx = mats[m].log_height;
         total_w += mats[m].width;
     }
-    uint32_t *buf = (uint32_t *)malloc(sizeof(uint32_t) * (total_w + 1));
     size_t H = (size_t)1 << mx;
-    for (size_t r = 0; r < H; r++) {
-        size_t k = gather_rows(mats, n, mx, r, buf);
-        orc_hash_slice(buf, k, digests + 8 * r);
+#pragma omp parallel
+    {
+        uint32_t *buf = (uint32_t *)malloc(sizeof(uint32_t) * (total_w + 1));
+#pragma omp for schedule(static)
+        for (size_t r = 0; r < H; r++) {
+            size_t k = gather_rows(mats, n, mx, r, buf);
+            orc_hash_slice(buf, k, digests + 8 * r);
+        }
+        free(buf);
     }
     uint32_t *prev = digests;
     for (unsigned lh = mx; lh-- > 0;) {
@@ -49,16 +54,21 @@ void orc_merkle_commit(const orc_matrix *mats, size_t n, uint32_t *digests) {
         uint32_t *cur = prev + 8 * (L * 2);
         int inject = 0;
         for (size_t m = 0; m < n; m++) if (mats[m].log_height == lh) inject = 1;
-        for (size_t i = 0; i < L; i++) {
-            orc_compress(prev + 8 * i, prev + 8 * (i + L), cur + 8 * i);
-            if (inject) {
-                uint32_t hr[8];
-                size_t k = gather_rows(mats, n, lh, i, buf);
-                orc_hash_slice(buf, k, hr);
-                orc_compress(cur + 8 * i, hr, cur + 8 * i);
+#pragma omp parallel if (L >= 256)
+        {
+            uint32_t *buf = (uint32_t *)malloc(sizeof(uint32_t) * (total_w + 1));
+#pragma omp for schedule(static)
+            for (size_t i = 0; i < L; i++) {
+                orc_compress(prev + 8 * i, prev + 8 * (i + L), cur + 8 * i);
+                if (inject) {
+                    uint32_t hr[8];
+                    size_t k = gather_rows(mats, n, lh, i, buf);
+                    orc_hash_slice(buf, k, hr);
+                    orc_compress(cur + 8 * i, hr, cur + 8 * i);
+                }
             }
+            free(buf);
         }
         prev = cur;
     }
-    free(buf);
 }

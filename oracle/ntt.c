@@ -49,6 +49,7 @@ void orc_idft(uint32_t *a, unsigned log_n) {
 void orc_coset_lde(const uint32_t *in, uint32_t *out, uint32_t width, unsigned log_n,
                    unsigned added_bits, uint32_t shift) {
     size_t n = (size_t)1 << log_n, m = (size_t)1 << (log_n + added_bits);
+#pragma omp parallel for schedule(dynamic)
     for (uint32_t c = 0; c < width; c++) {
         bb_t *o = out + (size_t)c * m;
         memcpy(o, in + (size_t)c * n, n * sizeof(bb_t));

@@ -26,7 +26,7 @@ static bb_t RC_INT[N_INT];
 static bb_t DIAG[16];
 static int inited = 0;
 
-static void init_constants(void) {
+__attribute__((constructor)) static void init_constants(void) {
     if (inited) return;
     static const char tag[] = "dvt-amd/poseidon2-babybear-w16/rc";
     size_t tl = sizeof(tag) - 1;

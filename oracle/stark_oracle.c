@@ -32,13 +32,16 @@ void orc_quotient(const orc_chip_air *chip, const uint32_t *main_lde, const uint
     for (uint32_t k = 1; k < nfold; k++) apow[k] = ef_mul(apow[k - 1], al);
     bpow[0] = be;
     for (uint32_t k = 1; k < chip->max_arity; k++) bpow[k] = ef_mul(bpow[k - 1], be);
+    const bb_t g = BB_GENERATOR, w2 = bb_two_adic_gen(log_n + 1), w_inv = bb_inv(bb_two_adic_gen(log_n));
+    const bb_t gn = bb_pow(g, n);
+#pragma omp parallel
+    {
     uint32_t *ml = malloc(4 * (chip->main_w + 1)), *mn = malloc(4 * (chip->main_w + 1));
     uint32_t *pl = malloc(4 * (chip->prep_w + 1)), *pn = malloc(4 * (chip->prep_w + 1));
     uint32_t *cv = malloc(4 * (nc + 1)), *mult = malloc(4 * (ni + 1)), *vals = malloc(4 * (size_t)(ni + 1) * chip->max_arity);
-    const bb_t g = BB_GENERATOR, w2 = bb_two_adic_gen(log_n + 1), w_inv = bb_inv(bb_two_adic_gen(log_n));
-    const bb_t gn = bb_pow(g, n);
-    bb_t x = g;
-    for (size_t i = 0; i < m; i++, x = bb_mul(x, w2)) {
+#pragma omp for schedule(static)
+    for (size_t i = 0; i < m; i++) {
+        const bb_t x = bb_mul(g, bb_pow(w2, i));
         const size_t inx = (i + 2) & (m - 1);
         for (uint32_t c = 0; c < chip->main_w; c++) { ml[c] = main_lde[(size_t)c * m + i]; mn[c] = main_lde[(size_t)c * m + inx]; }
         for (uint32_t c = 0; c < chip->prep_w; c++) { pl[c] = prep_lde[(size_t)c * m + i]; pn[c] = prep_lde[(size_t)c * m + inx]; }
@@ -88,7 +91,9 @@ void orc_quotient(const orc_chip_air *chip, const uint32_t *main_lde, const uint
         uint32_t *o = out + ((i & 1) ? 4 * n : 0) + (i >> 1);
         for (int k = 0; k < 4; k++) o[(size_t)k * n] = q.c[k];
     }
-    free(apow); free(bpow); free(ml); free(mn); free(pl); free(pn); free(cv); free(mult); free(vals);
+    free(ml); free(mn); free(pl); free(pn); free(cv); free(mult); free(vals);
+    }
+    free(apow); free(bpow);
 }
 
 /* K6.  cols [width][N]: evaluations over coset_shift * <w_N>.  out[c] = p_c(z) in F_p^4.
@@ -96,9 +101,10 @@ void orc_quotient(const orc_chip_air *chip, const uint32_t *main_lde, const uint
 void orc_eval_columns(const uint32_t *cols, uint32_t width, uint32_t log_n, uint32_t coset_shift, const uint32_t z[4], uint32_t *out) {
     const size_t n = (size_t)1 << log_n;
     ef_t zz = ef_load(z);
-    bb_t *co = malloc(4 * n);
     const bb_t sinv = bb_inv(coset_shift);
+#pragma omp parallel for schedule(dynamic)
     for (uint32_t c = 0; c < width; c++) {
+        bb_t *co = malloc(4 * n);
         memcpy(co, cols + (size_t)c * n, 4 * n);
         orc_idft(co, log_n);
         bb_t s = 1;
@@ -106,8 +112,8 @@ void orc_eval_columns(const uint32_t *cols, uint32_t width, uint32_t log_n, uint
         ef_t acc = ef_zero();
         for (size_t k = n; k-- > 0;) acc = ef_add(ef_mul(acc, zz), ef_from_base(co[k]));
         ef_store(out + 4 * c, acc);
+        free(co);
     }
-    free(co);
 }
 
 /* K7.  cols: n_all LDE columns of height 2^log_m on 31*<w_M>, the first n_two opened at zeta and zeta_next.
@@ -122,8 +128,9 @@ void orc_reduced_opening(const uint32_t *const *cols, uint32_t n_two, uint32_t n
     apow[0] = ef_one();
     for (uint32_t k = 1; k <= n_all; k++) apow[k] = ef_mul(apow[k - 1], al);
     const bb_t w = bb_two_adic_gen(log_m);
-    bb_t x = BB_GENERATOR;
-    for (size_t i = 0; i < m; i++, x = bb_mul(x, w)) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < m; i++) {
+        const bb_t x = bb_mul(BB_GENERATOR, bb_pow(w, i));
         ef_t s1 = ef_zero(), s2 = ef_zero();
         for (uint32_t c = 0; c < n_all; c++) {
             bb_t px = cols[c][i];
@@ -142,8 +149,9 @@ void orc_fri_fold(const uint32_t *v, uint32_t log_m, const uint32_t beta[4], con
     const size_t half = (size_t)1 << (log_m - 1);
     ef_t be = ef_load(beta);
     const bb_t inv2 = bb_inv(2), winv = bb_inv(bb_two_adic_gen(log_m));
-    bb_t xi = 1;
-    for (size_t i = 0; i < half; i++, xi = bb_mul(xi, winv)) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < half; i++) {
+        const bb_t xi = bb_pow(winv, i);
         ef_t lo = ef_load(v + 4 * i), hi = ef_load(v + 4 * (i + half));
         ef_t r = ef_add(ef_mul_base(ef_add(lo, hi), inv2), ef_mul(be, ef_mul_base(ef_sub(lo, hi), bb_mul(inv2, xi))));
         if (ro) r = ef_add(r, ef_load(ro + 4 * i));
