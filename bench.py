@@ -76,22 +76,17 @@ def main():
     from dvt_circuits_amd import capi
     from tests import guests
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from dvt_circuits_amd.dist_util import Ranks, whole_job_rate
+
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-
-        dist = dist_mod
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    ranks = Ranks(backend="nccl", device=torch.device("cuda", local))   # nccl == RCCL on ROCm
+    rank, world = ranks.rank, ranks.world
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
     def barrier():
-        if dist:
-            dist.barrier()
+        ranks.barrier()
         torch.cuda.synchronize()
 
     elf, want_pv = guests.bignum(args.iters)
@@ -115,11 +110,7 @@ def main():
         prover.prove_job(pk, job, want_bytes=False)
     prover.sync()
     barrier()
-    dt = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = ranks.max_over_ranks(time.perf_counter() - t0)
 
     # end-to-end rate including host execution + PCIe upload (reported, never `value`)
     t1 = time.perf_counter()
@@ -144,7 +135,7 @@ def main():
 
     out = {
         "metric": "SP1 prover cycles/sec + proofs/hour, finalization_prove at 1/2/4/8 MI355X",
-        "value": world * cycles * args.steps / dt,
+        "value": whole_job_rate(cycles, world, args.steps, dt),
         "unit": "guest cycles/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -192,8 +183,7 @@ def main():
     prover.job_free(job)
     prover.pk_free(pk)
     prover.close()
-    if dist:
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,59 @@
+"""CPU tests of the N > 1 bench path (world size 2, gloo) and of the bench line contract."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys, time
+sys.path.insert(0, %r)
+from dvt_circuits_amd.dist_util import Ranks, whole_job_rate
+r = Ranks(backend="gloo")
+r.barrier()
+t0 = time.perf_counter()
+time.sleep(0.05 * (r.rank + 1))          # rank 1 is slower: the reported time must be its time
+dt = r.max_over_ranks(time.perf_counter() - t0)
+r.barrier()
+mine = r.shard_of(5)
+if r.rank == 0:
+    print("RESULT", r.world, round(dt, 2) >= 0.1, mine, whole_job_rate(1000, r.world, 2, 1.0))
+else:
+    print("OTHER", mine)
+r.close()
+"""
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_world_size_2_gloo_barrier_max_and_sharding():
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "RESULT 2 True [0, 2, 4] 4000.0" in outs[0][0]
+    assert "OTHER [1, 3]" in outs[1][0]
+
+
+def test_bench_line_fields_of_committed_profile():
+    """the committed round-1 bench line carries every field of the contract"""
+    line = json.load(open(os.path.join(ROOT, "profiles", "r1_bench_line.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["vs_baseline"] is None and "workload" in line["config"]
+    r = line["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = line["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
