@@ -47,8 +47,11 @@ struct Fp {
         uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
         uint32_t t = lo * MONTY_MU;
         uint32_t u = mulhi_u32(t, P);
-        uint32_t r = hi - u;
-        return hi < u ? r + P : r;
+        // hi - u lies in (-p, p); add p when it is negative.  Written as an unsigned min so that hipcc
+        // emits v_sub / v_add / v_min instead of a 64-bit compare + select: if hi >= u then r < p and
+        // r + p does not wrap (so min = r); otherwise r = 2^32 - d wraps high and r + p = p - d is smaller.
+        uint32_t r = hi - u, r2 = r + P;
+        return r2 < r ? r2 : r;
     }
     DVT_HD static Fp from_canonical(uint32_t c) { return raw(reduce64((uint64_t)c * MONTY_R2)); }
     DVT_HD static Fp from_u64(uint64_t c) { return from_canonical((uint32_t)(c % P)); }

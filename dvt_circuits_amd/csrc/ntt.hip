@@ -7,7 +7,7 @@
 // Decomposition (four-step on both transforms, fused in the middle), with
 // N = N1*N2, N2 = 2^min(n,12), M2 = 2*N2, M = 2N = N1*M2:
 //   P1  ntt_strided<inverse>   for every n2: N1-point inverse DFT over the
-//                              stride-N2 samples, times w_N^(-n2*k1); in place.
+//                              stride-N2 samples, times w_N^(-n2*k1).
 //                              LDS tile = N1 x 2^b (2^b consecutive n2 -> 64..128-B
 //                              coalesced HBM segments).               [n > 12 only]
 //   P2  lde_block              for every k1: N2-point inverse DFT of the contiguous
@@ -21,9 +21,12 @@
 //
 // Inverse transforms are computed as forward DFTs with the output index negated
 // (iDFT(x)[k] = DFT(x)[-k]/N), so one forward twiddle table per kernel suffices.
-// Local transforms: radix-2 DIF (natural in, bit-reversed out) / DIT (bit-reversed
-// in, natural out) in LDS with an LDS-resident twiddle table; the bit reversals
-// are absorbed into LDS addressing, never into HBM addressing.
+// Local transforms: DIF (natural in, bit-reversed out) / DIT (bit-reversed in,
+// natural out) in LDS with an LDS-resident twiddle table; the bit reversals are
+// absorbed into LDS addressing, never into HBM addressing.  Butterflies run in
+// registers, three stages (radix 8) per LDS round trip: a thread gathers the 8
+// words of a group, does 12 butterflies, scatters them back — one barrier per three
+// stages instead of per stage.
 #include "kernels.h"
 
 namespace dvt {
@@ -36,12 +39,91 @@ __device__ __forceinline__ Fp shift_pow(const NttTables &t, uint32_t k) {  // 31
 }
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
 
+// ---- fused radix-2^R passes over an LDS array ------------------------------------------------
+// Element (i, c) of a [2^L][2^log_cols] tile lives at sm[(i << log_cols) | c]; the transform runs
+// over i for every c.  tw[e << tw_shift] = w_{2^L}^e.
+// DIF stages s .. s+R-1 (stage t pairs distance 2^(L-1-t), twiddle exponent (index mod half) << t).
+template <int R>
+__device__ __forceinline__ void dif_pass(Fp *sm, const Fp *tw, uint32_t L, uint32_t s, uint32_t tw_shift, uint32_t log_cols,
+                                         uint32_t tid, uint32_t nt) {
+    constexpr uint32_t G = 1u << R;
+    const uint32_t lh_last = L - s - R, h_last = 1u << lh_last, cmask = (1u << log_cols) - 1;
+    const uint32_t work = (1u << (L - R)) << log_cols;
+    for (uint32_t w = tid; w < work; w += nt) {
+        const uint32_t c = w & cmask, g = w >> log_cols;
+        const uint32_t r = g & (h_last - 1), blk = g >> lh_last;
+        const uint32_t base = (blk << (L - s)) | r;
+        Fp v[G];
+#pragma unroll
+        for (uint32_t j = 0; j < G; j++) v[j] = sm[((base + (j << lh_last)) << log_cols) | c];
+#pragma unroll
+        for (uint32_t t = 0; t < (uint32_t)R; t++) {
+            const uint32_t dist = G >> (t + 1);
+#pragma unroll
+            for (uint32_t j = 0; j < G; j++) {
+                if (j & dist) continue;
+                const uint32_t lo = ((j & (dist - 1)) << lh_last) | r;
+                Fp a = v[j], b = v[j + dist];
+                v[j] = a + b;
+                v[j + dist] = (a - b) * tw[(lo << (s + t)) << tw_shift];
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < G; j++) sm[((base + (j << lh_last)) << log_cols) | c] = v[j];
+    }
+}
+// DIT stages s .. s+R-1 (stage t pairs distance 2^t, twiddle exponent (index mod 2^t) << (L-1-t)).
+template <int R>
+__device__ __forceinline__ void dit_pass(Fp *sm, const Fp *tw, uint32_t L, uint32_t s, uint32_t tw_shift, uint32_t tid, uint32_t nt) {
+    constexpr uint32_t G = 1u << R;
+    const uint32_t h0 = 1u << s;
+    const uint32_t work = 1u << (L - R);
+    for (uint32_t g = tid; g < work; g += nt) {
+        const uint32_t r = g & (h0 - 1), blk = g >> s;
+        const uint32_t base = (blk << (s + R)) | r;
+        Fp v[G];
+#pragma unroll
+        for (uint32_t j = 0; j < G; j++) v[j] = sm[base + (j << s)];
+#pragma unroll
+        for (uint32_t t = 0; t < (uint32_t)R; t++) {
+            const uint32_t dist = 1u << t;
+#pragma unroll
+            for (uint32_t j = 0; j < G; j++) {
+                if (j & dist) continue;
+                const uint32_t lo = ((j & (dist - 1)) << s) | r;
+                Fp a = v[j], b = v[j + dist] * tw[(lo << (L - 1 - s - t)) << tw_shift];
+                v[j] = a + b;
+                v[j + dist] = a - b;
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < G; j++) sm[base + (j << s)] = v[j];
+    }
+}
+template <bool DIF>
+__device__ __forceinline__ void run_stages(Fp *sm, const Fp *tw, uint32_t L, uint32_t first, uint32_t count, uint32_t tw_shift,
+                                           uint32_t log_cols, uint32_t tid, uint32_t nt) {
+    uint32_t s = first, left = count;
+    while (left) {
+        if (left >= 3) {
+            if (DIF) dif_pass<3>(sm, tw, L, s, tw_shift, log_cols, tid, nt); else dit_pass<3>(sm, tw, L, s, tw_shift, tid, nt);
+            s += 3; left -= 3;
+        } else if (left == 2) {
+            if (DIF) dif_pass<2>(sm, tw, L, s, tw_shift, log_cols, tid, nt); else dit_pass<2>(sm, tw, L, s, tw_shift, tid, nt);
+            s += 2; left -= 2;
+        } else {
+            if (DIF) dif_pass<1>(sm, tw, L, s, tw_shift, log_cols, tid, nt); else dit_pass<1>(sm, tw, L, s, tw_shift, tid, nt);
+            s += 1; left -= 1;
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------- P1 / P3
 // grid.x = row_stride >> log_cols (tiles along the contiguous axis), grid.y = column
 template <bool INVERSE>
 __global__ void __launch_bounds__(256) ntt_strided_kernel(const uint32_t *src, uint32_t *data, size_t col_stride, uint32_t log_rows,
-                                                         uint32_t row_stride, uint32_t log_cols, uint32_t log_n,
-                                                         NttTables tabs) {
+                                                         uint32_t row_stride, uint32_t log_cols, uint32_t log_n, NttTables tabs) {
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t rows = 1u << log_rows, cols = 1u << log_cols, cmask = cols - 1;
     const uint32_t tile_elems = rows << log_cols;
@@ -58,20 +140,7 @@ __global__ void __launch_bounds__(256) ntt_strided_kernel(const uint32_t *src, u
         sm[idx] = Fp::raw(scol[(size_t)r * row_stride + c0 + c]);
     }
     __syncthreads();
-    // forward DIF over the row index
-    for (uint32_t s = 0; s < log_rows; s++) {
-        const uint32_t lh = log_rows - 1 - s, half = 1u << lh;
-        for (uint32_t w = tid; w < tile_elems / 2; w += nt) {
-            uint32_t c = w & cmask, b = w >> log_cols;
-            uint32_t lo = b & (half - 1);
-            uint32_t i = ((b >> lh) << (lh + 1)) | lo;
-            uint32_t ia = (i << log_cols) | c, ib = ((i + half) << log_cols) | c;
-            Fp u = sm[ia], v = sm[ib];
-            sm[ia] = u + v;
-            sm[ib] = (u - v) * tw[lo << s];
-        }
-        __syncthreads();
-    }
+    run_stages<true>(sm, tw, log_rows, 0, log_rows, 0, log_cols, tid, nt);  // forward DIF over the row index
     for (uint32_t idx = tid; idx < tile_elems; idx += nt) {
         uint32_t q = idx >> log_cols, c = idx & cmask;
         uint32_t kf = bitrev(q, log_rows);
@@ -90,9 +159,8 @@ __global__ void __launch_bounds__(256) ntt_strided_kernel(const uint32_t *src, u
 
 // ---------------------------------------------------------------- P2
 // grid.x = N1 (block index k1), grid.y = column.  blockDim.x = 256, N2 <= 4096.
-__global__ void __launch_bounds__(256) lde_block_kernel(const uint32_t *in, uint32_t *out, uint32_t log_n,
-                                                       uint32_t log_n1, uint32_t shift_mode, uint32_t ninv_m,
-                                                       NttTables tabs) {
+__global__ void __launch_bounds__(256) lde_block_kernel(const uint32_t *in, uint32_t *out, uint32_t log_n, uint32_t log_n1,
+                                                       uint32_t shift_mode, uint32_t ninv_m, NttTables tabs) {
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t log_n2 = log_n - log_n1, n2 = 1u << log_n2, m2 = n2 * 2, log_m2 = log_n2 + 1;
     const uint32_t log_m = log_n + 1;
@@ -105,18 +173,7 @@ __global__ void __launch_bounds__(256) lde_block_kernel(const uint32_t *in, uint
     for (uint32_t e = tid; e < n2; e += nt) tw[e] = root_pow24(tabs, e << (24 - log_m2));
     for (uint32_t i = tid; i < n2; i += nt) sm[i] = Fp::raw(src[i]);
     __syncthreads();
-    // forward DIF of size N2 (w_N2^e = tw[2e])
-    for (uint32_t s = 0; s < log_n2; s++) {
-        const uint32_t lh = log_n2 - 1 - s, half = 1u << lh;
-        for (uint32_t b = tid; b < n2 / 2; b += nt) {
-            uint32_t lo = b & (half - 1);
-            uint32_t i = ((b >> lh) << (lh + 1)) | lo;
-            Fp u = sm[i], v = sm[i + half];
-            sm[i] = u + v;
-            sm[i + half] = (u - v) * tw[lo << (s + 1)];
-        }
-        __syncthreads();
-    }
+    run_stages<true>(sm, tw, log_n2, 0, log_n2, 1, 0, tid, nt);  // forward DIF of size N2 (w_N2^e = tw[2e])
     // position q holds DFT[bitrev(q)] = N * coeff[(N2 - bitrev(q)) mod N2 (+ block k1)];
     // scale, then place at the bit-reversed slot of the zero-padded M2 array with the
     // first DIT stage (pairs (c,0) -> (c,c)) folded in.
@@ -146,18 +203,7 @@ __global__ void __launch_bounds__(256) lde_block_kernel(const uint32_t *in, uint
         }
     }
     __syncthreads();
-    // remaining DIT stages of the M2-point forward transform
-    for (uint32_t s = 1; s < log_m2; s++) {
-        const uint32_t half = 1u << s;
-        for (uint32_t b = tid; b < m2 / 2; b += nt) {
-            uint32_t lo = b & (half - 1);
-            uint32_t i = ((b >> s) << (s + 1)) | lo;
-            Fp u = sm[i], v = sm[i + half] * tw[lo << (log_m2 - 1 - s)];
-            sm[i] = u + v;
-            sm[i + half] = u - v;
-        }
-        __syncthreads();
-    }
+    run_stages<false>(sm, tw, log_m2, 1, log_m2 - 1, 0, 0, tid, nt);  // remaining DIT stages of the M2-point transform
     for (uint32_t j2 = tid; j2 < m2; j2 += nt) {
         Fp val = sm[j2];
         if (log_n1) {
