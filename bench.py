@@ -39,10 +39,11 @@ def cpu_baseline(small_iters, big_iters):
     pts = []
     for it in (small_iters, big_iters):
         elf, _ = guests.bignum(it)
-        chips, pubs = capi.rv32_debug_traces(elf)
+        chips, pubs, _ = capi.rv32_debug_traces(elf)
         cyc = capi.execute(elf)[1]["cycles"]
         t = time.perf_counter()
-        _oracle_prover.prove_shard("rv32", chips, pubs, 100, 4)
+        gc = _oracle_prover.global_challenges(_oracle_prover.prep_root_of(chips), [_oracle_prover.main_root(chips) + [int(x) for x in pubs]])
+        _oracle_prover.prove_shard("rv32", chips, pubs, 100, 4, perm_challenges=gc)
         pts.append((cyc, time.perf_counter() - t))
     (c0, t0), (c1, t1) = pts
     from tests import _orc

@@ -86,7 +86,14 @@ def load():
     lib.dvt_rv32_prove_job.argtypes = [vp, vp, vp, C.POINTER(u8p), C.POINTER(sz)]
     lib.dvt_job_free.argtypes = [vp, vp]
     lib.dvt_job_free.restype = None
-    lib.dvt_rv32_debug_traces.argtypes = [C.c_char_p, sz, C.POINTER(Buf), sz, C.POINTER(u32p), C.POINTER(sz), C.POINTER(C.c_char_p)]
+    lib.dvt_rv32_debug_traces.argtypes = [C.c_char_p, sz, C.POINTER(Buf), sz, u32, u32, u32p, C.POINTER(u32p), C.POINTER(sz), C.POINTER(C.c_char_p)]
+    lib.dvt_rv32_job_shards.argtypes = [vp]
+    lib.dvt_rv32_job_shards.restype = sz
+    lib.dvt_rv32_commit_shard.argtypes = [vp, vp, vp, sz, u32p]
+    lib.dvt_rv32_challenges.argtypes = [C.c_char_p, sz, u32p, sz, u32p]
+    lib.dvt_rv32_prove_shard.argtypes = [vp, vp, vp, sz, u32p, C.POINTER(u8p), C.POINTER(sz)]
+    lib.dvt_rv32_assemble.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(sz), sz, C.POINTER(u8p), C.POINTER(sz)]
+    lib.dvt_rv32_debug_device_traces.argtypes = [vp, vp, vp, sz, C.POINTER(u32p), C.POINTER(sz)]
     _lib = lib
     return lib
 
@@ -135,16 +142,7 @@ def verify(vk: bytes, proof: bytes, fri_queries=100, pow_bits=16):
     return rc == DVT_OK, ec.value, out, _take_str(lib, why)
 
 
-def rv32_debug_traces(elf: bytes, stdin=()):
-    """Host-only: the traces the prover would commit.  Returns (chips, pubs) where
-    chips = list of dict(chip_id, log_n, main [w][n], prep [w][n])."""
-    lib = load()
-    blob, n, err = u32p(), C.c_size_t(), C.c_char_p()
-    rc = lib.dvt_rv32_debug_traces(elf, len(elf), _bufs(stdin), len(stdin), C.byref(blob), C.byref(n), C.byref(err))
-    if rc:
-        raise DvtError(rc, _take_str(lib, err))
-    w = np.ctypeslib.as_array(blob, shape=(n.value,)).copy()
-    lib.dvt_free(C.cast(blob, C.c_void_p))
+def _parse_blob(w):
     nch = int(w[0])
     meta = w[1:1 + 4 * nch].reshape(nch, 4)
     at = 1 + 4 * nch
@@ -161,6 +159,31 @@ def rv32_debug_traces(elf: bytes, stdin=()):
         chips.append(dict(chip_id=int(cid), log_n=int(lg), main=main, prep=prep))
     assert at == len(w)
     return chips, pubs
+
+
+def rv32_debug_traces(elf: bytes, stdin=(), log_shard=0, shard=0):
+    """Host-only: the traces the prover would commit for shard `shard` (0-based) of the run cut at
+    2^log_shard cycles.  Returns (chips, pubs, n_shards); chips = list of dict(chip_id, log_n, main, prep)."""
+    lib = load()
+    blob, n, err, ns = u32p(), C.c_size_t(), C.c_char_p(), C.c_uint32()
+    rc = lib.dvt_rv32_debug_traces(elf, len(elf), _bufs(stdin), len(stdin), log_shard, shard, C.byref(ns), C.byref(blob), C.byref(n), C.byref(err))
+    if rc:
+        raise DvtError(rc, _take_str(lib, err))
+    w = np.ctypeslib.as_array(blob, shape=(n.value,)).copy()
+    lib.dvt_free(C.cast(blob, C.c_void_p))
+    chips, pubs = _parse_blob(w)
+    return chips, pubs, ns.value
+
+
+def rv32_challenges(vk: bytes, headers):
+    """Host-only: the LogUp challenges common to all shards, from their 13-word headers (in shard order)."""
+    lib = load()
+    h = np.ascontiguousarray(headers, dtype=np.uint32).reshape(-1, 13)
+    out = np.zeros(8, np.uint32)
+    rc = lib.dvt_rv32_challenges(vk, len(vk), h.ctypes.data_as(u32p), h.shape[0], out.ctypes.data_as(u32p))
+    if rc:
+        raise DvtError(rc, "dvt_rv32_challenges")
+    return out
 
 
 def _traces(traces):
@@ -306,25 +329,45 @@ class Prover:
         self.lib.dvt_free(C.cast(out, C.c_void_p))
         return b
 
-    def debug_device_traces(self, pk, job):
-        """K0 on the device, traces downloaded (canonical): list of dict(chip_id, log_n, main), pubs"""
-        self.lib.dvt_rv32_debug_device_traces.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(u32p), C.POINTER(C.c_size_t)]
+    def debug_device_traces(self, pk, job, shard=0):
+        """K0 on the device for one shard, traces downloaded (canonical): (chips, pubs)"""
         blob, n = u32p(), C.c_size_t()
-        self.check(self.lib.dvt_rv32_debug_device_traces(self.h, pk, job, C.byref(blob), C.byref(n)))
+        self.check(self.lib.dvt_rv32_debug_device_traces(self.h, pk, job, shard, C.byref(blob), C.byref(n)))
         w = np.ctypeslib.as_array(blob, shape=(n.value,)).copy()
         self.lib.dvt_free(C.cast(blob, C.c_void_p))
-        nch = int(w[0])
-        meta = w[1:1 + 4 * nch].reshape(nch, 4)
-        at = 1 + 4 * nch
-        npub = int(w[at])
-        pubs = w[at + 1:at + 1 + npub].copy()
-        at += 1 + npub
-        chips = []
-        for cid, lg, mw, _ in meta:
-            h = 1 << int(lg)
-            chips.append(dict(chip_id=int(cid), log_n=int(lg), main=w[at:at + int(mw) * h].reshape(int(mw), h)))
-            at += int(mw) * h
-        return chips, pubs
+        return _parse_blob(w)
+
+    # ---- shard-level API (multi-GPU: ranks own shards; the headers are the only thing exchanged)
+    def job_shards(self, job):
+        return int(self.lib.dvt_rv32_job_shards(job))
+
+    def commit_shard(self, pk, job, shard):
+        h = np.zeros(13, np.uint32)
+        self.check(self.lib.dvt_rv32_commit_shard(self.h, pk, job, shard, h.ctypes.data_as(u32p)))
+        return h
+
+    def prove_shard(self, pk, job, shard, challenges, want_bytes=True):
+        ch = np.ascontiguousarray(challenges, dtype=np.uint32)
+        if not want_bytes:
+            self.check(self.lib.dvt_rv32_prove_shard(self.h, pk, job, shard, ch.ctypes.data_as(u32p), None, None))
+            return None
+        out, n = u8p(), C.c_size_t()
+        self.check(self.lib.dvt_rv32_prove_shard(self.h, pk, job, shard, ch.ctypes.data_as(u32p), C.byref(out), C.byref(n)))
+        b = C.string_at(out, n.value)
+        self.lib.dvt_free(C.cast(out, C.c_void_p))
+        return b
+
+    def assemble(self, job, shard_proofs):
+        n = len(shard_proofs)
+        arr = (C.c_char_p * n)(*shard_proofs)
+        lens = (C.c_size_t * n)(*[len(x) for x in shard_proofs])
+        out, m = u8p(), C.c_size_t()
+        rc = self.lib.dvt_rv32_assemble(job, arr, lens, n, C.byref(out), C.byref(m))
+        if rc:
+            raise DvtError(rc, "dvt_rv32_assemble")
+        b = C.string_at(out, m.value)
+        self.lib.dvt_free(C.cast(out, C.c_void_p))
+        return b
 
     def job_free(self, job):
         self.lib.dvt_job_free(self.h, job)

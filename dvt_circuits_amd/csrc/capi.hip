@@ -18,6 +18,8 @@ using namespace dvt;
 struct dvt_prover {
     Engine eng;
     StarkConfig cfg;
+    uint32_t log_shard = 21;          // cycles per shard = 2^log_shard (SP1's default shard size)
+    uint64_t max_cycles = 1ull << 36;
     std::string err;
     std::mutex mu;
 };
@@ -29,17 +31,6 @@ struct dvt_pk {
     rv32::Instr *d_instrs = nullptr;   // device copy of prog.instrs (K0)
     uint32_t *d_prog_row = nullptr;    // instruction index -> program-table row
 };
-// one prepared shard: executor output resident in HBM, ready for K0..K9
-struct dvt_job {
-    rv32::ExecResult res;              // recs are released after the upload
-    rv32::CycleRec *d_recs = nullptr;
-    size_t n_recs = 0;
-    uint32_t log_n[5] = {0, 0, 0, 0, 0};
-    uint32_t *d_aux[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // main traces except cpu (Montgomery)
-    uint32_t *d_cpu = nullptr;         // generated by K0 inside prove_job
-    std::vector<Fp> pubs;
-};
-
 static thread_local std::string g_create_err;
 
 static int fail(dvt_prover *p, int code, const char *fmt, ...) {
@@ -147,6 +138,8 @@ int dvt_prover_create(const char *cfg_json, dvt_prover **out) {
     p->cfg.num_queries = (uint32_t)cfg_int(cfg_json, "fri_queries", 100);
     p->cfg.pow_bits = (uint32_t)cfg_int(cfg_json, "pow_bits", 16);
     p->eng.profile = cfg_int(cfg_json, "profile", 0) != 0;
+    p->log_shard = (uint32_t)cfg_int(cfg_json, "log_shard_size", 21);
+    if (p->log_shard < 4 || p->log_shard > 22) { delete p; return fail(nullptr, DVT_ERR_INPUT, "log_shard_size must be 4..22"); }
     if (p->cfg.num_queries == 0 || p->cfg.num_queries > 1024 || p->cfg.pow_bits > 30) {
         delete p;
         return fail(nullptr, DVT_ERR_INPUT, "fri_queries must be 1..1024 and pow_bits <= 30");
@@ -378,8 +371,9 @@ int dvt_last_stage_ms(dvt_prover *p, float out[6]) {
 
 // ====================================================================== rv32 boundary
 namespace {
-constexpr uint32_t CORE_PROOF_MAGIC = 0x31435644u;  // "DVC1"
-constexpr uint64_t SINGLE_SHARD_MAX_CYCLES = 1ull << 22;
+constexpr uint32_t CORE_PROOF_MAGIC = 0x32435644u;  // "DVC2"
+constexpr uint32_t N_PUB = 5;                        // start_pc, next_pc, exit_code, shard, is_last
+constexpr uint32_t HEADER_WORDS = 8 + N_PUB;         // per-shard commitment header: main root + public values (canonical)
 
 std::vector<std::vector<uint8_t>> collect_stdin(const dvt_buf *bufs, size_t n) {
     std::vector<std::vector<uint8_t>> v(n);
@@ -400,7 +394,183 @@ uint8_t *dup_bytes(const std::vector<uint8_t> &v, size_t *len) {
     if (len) *len = v.size();
     return b;
 }
+// LogUp challenges common to all shards: transcript over the key and every shard's header
+PermChallenges global_challenges(const VerifyingKey &vk, const uint32_t *headers, size_t n) {
+    Challenger g;
+    g.observe(vk.prep_root);
+    g.observe_u32((uint32_t)n);
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t *h = headers + i * HEADER_WORDS;
+        for (uint32_t k = 0; k < 8; k++) g.observe(Fp::from_canonical(h[k]));
+        g.observe_u32(N_PUB);
+        for (uint32_t k = 0; k < N_PUB; k++) g.observe(Fp::from_canonical(h[8 + k] % P));
+    }
+    PermChallenges c;
+    c.alpha = g.sample_ext();
+    c.beta = g.sample_ext();
+    return c;
+}
 }  // namespace
+
+struct ShardJob {
+    uint32_t index = 0;
+    size_t n_recs = 0;
+    rv32::CycleRec *d_recs = nullptr;
+    uint32_t log_n[5] = {0, 0, 0, 0, 0};
+    bool present[5] = {false, false, false, false, false};
+    uint32_t *d_aux[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // main traces except cpu
+    std::vector<Fp> pubs;
+};
+// one prepared execution: executor output cut into shards, resident in HBM, ready for K0..K9
+struct dvt_job {
+    rv32::ExecResult res;  // per-cycle records are released after the upload
+    std::vector<ShardJob> shards;
+    uint32_t *d_cpu = nullptr, *d_byte = nullptr, *d_prog = nullptr;  // working buffers (largest shard)
+    size_t byte_words = 0, prog_words = 0;
+};
+
+static void job_release(dvt_job *j) {
+    if (!j) return;
+    for (auto &s : j->shards) {
+        if (s.d_recs) (void)hipFree(s.d_recs);
+        for (auto &d : s.d_aux) if (d) (void)hipFree(d);
+    }
+    if (j->d_cpu) (void)hipFree(j->d_cpu);
+    if (j->d_byte) (void)hipFree(j->d_byte);
+    if (j->d_prog) (void)hipFree(j->d_prog);
+    delete j;
+}
+
+// execute + auxiliary traces + upload (no lock: callers hold p->mu)
+static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_bufs, size_t nbuf, dvt_job **out, dvt_report *report) {
+    HIP_TRY(p, hipSetDevice(p->eng.device));
+    dvt_job *j = new dvt_job();
+    rv32::execute(pk->prog, collect_stdin(stdin_bufs, nbuf), true, p->max_cycles, p->log_shard, &j->res);
+    fill_report(report, j->res);
+    int rc = DVT_OK;
+    if (!j->res.error.empty()) rc = fail(p, DVT_ERR_GUEST, "guest trapped: %s", j->res.error.c_str());
+    else if (j->res.exit_code != 0) rc = fail(p, DVT_ERR_GUEST, "guest halted with exit code %d", j->res.exit_code);
+    else if (j->res.unsupported) rc = fail(p, DVT_ERR_UNSUPPORTED, "no chip for %s", j->res.unsupported_what.c_str());
+    if (rc) { job_release(j); return rc; }
+    const MachineDesc *m = machine_rv32();
+    uint32_t max_log_cpu = 0;
+    bool ok = true;
+    for (size_t si = 0; ok && si < j->res.shards.size(); si++) {
+        rv32::HostTraces T;
+        std::string err;
+        if (!rv32::build_aux_host(pk->prog, j->res, si, pk->prep, &T, &err)) { job_release(j); return fail(p, DVT_ERR_UNSUPPORTED, "%s", err.c_str()); }
+        ShardJob s;
+        auto &recs = j->res.shards[si].recs;
+        s.index = j->res.shards[si].index;
+        s.n_recs = recs.size();
+        for (int c = 0; c < m->n_chips; c++) { s.log_n[c] = T.log_n[c]; s.present[c] = T.present[c]; }
+        max_log_cpu = std::max(max_log_cpu, s.log_n[RV32_CHIP_CPU]);
+        ok = hipMalloc(&s.d_recs, s.n_recs * sizeof(rv32::CycleRec)) == hipSuccess &&
+             hipMemcpy(s.d_recs, recs.data(), s.n_recs * sizeof(rv32::CycleRec), hipMemcpyHostToDevice) == hipSuccess;
+        for (int c = 0; ok && c < m->n_chips; c++) {
+            if (c == RV32_CHIP_CPU || !s.present[c]) continue;
+            size_t words = T.main[c].size();
+            ok = hipMalloc(&s.d_aux[c], words * 4) == hipSuccess && hipMemcpy(s.d_aux[c], T.main[c].data(), words * 4, hipMemcpyHostToDevice) == hipSuccess;
+            // byte / program multiplicities stay plain integers until K0 has added the cpu rows' lookups
+            if (ok && c != RV32_CHIP_BYTE && c != RV32_CHIP_PROGRAM) ok = launch_to_internal(p->eng.stream, s.d_aux[c], words) == hipSuccess;
+        }
+        for (auto x : T.pubs) s.pubs.push_back(Fp::from_canonical(x));
+        std::vector<rv32::CycleRec>().swap(recs);
+        j->shards.push_back(std::move(s));
+    }
+    j->byte_words = (size_t)rv32::N_BYTE_OPS * 65536;
+    j->prog_words = (size_t)1 << pk->prep.log_n[RV32_CHIP_PROGRAM];
+    if (ok) ok = hipMalloc(&j->d_cpu, ((size_t)RV32_CPU_MAIN_W << max_log_cpu) * 4) == hipSuccess &&
+                 hipMalloc(&j->d_byte, j->byte_words * 4) == hipSuccess && hipMalloc(&j->d_prog, j->prog_words * 4) == hipSuccess;
+    if (ok) ok = hipStreamSynchronize(p->eng.stream) == hipSuccess;
+    if (!ok) { job_release(j); return fail(p, DVT_ERR_DEVICE, "uploading the shards to the device failed"); }
+    *out = j;
+    return DVT_OK;
+}
+
+// K0 of shard i into the job's working buffers; fills the chip trace list of that shard
+static int shard_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *j, size_t i, std::vector<ChipTrace> *traces) {
+    hipStream_t st = p->eng.stream;
+    ShardJob &s = j->shards[i];
+    const MachineDesc *m = machine_rv32();
+    bool ok = hipMemcpyAsync(j->d_byte, s.d_aux[RV32_CHIP_BYTE], j->byte_words * 4, hipMemcpyDeviceToDevice, st) == hipSuccess &&
+              hipMemcpyAsync(j->d_prog, s.d_aux[RV32_CHIP_PROGRAM], j->prog_words * 4, hipMemcpyDeviceToDevice, st) == hipSuccess &&
+              rv32::launch_k0_cpu_rows(st, s.d_recs, s.n_recs, s.index, pk->d_instrs, pk->d_prog_row, j->d_cpu, s.log_n[RV32_CHIP_CPU], j->d_byte,
+                                       j->d_prog) == hipSuccess &&
+              launch_to_internal(st, j->d_byte, j->byte_words) == hipSuccess && launch_to_internal(st, j->d_prog, j->prog_words) == hipSuccess;
+    if (!ok) return fail(p, DVT_ERR_DEVICE, "trace generation (K0) failed: %s", hipGetErrorString(hipGetLastError()));
+    traces->clear();
+    for (int c = 0; c < m->n_chips; c++) {
+        if (!s.present[c]) continue;
+        const uint32_t *ptr = c == RV32_CHIP_CPU ? j->d_cpu : c == RV32_CHIP_BYTE ? j->d_byte : c == RV32_CHIP_PROGRAM ? j->d_prog : s.d_aux[c];
+        traces->push_back({c, s.log_n[c], ptr});
+    }
+    return DVT_OK;
+}
+
+static int shard_commit(dvt_prover *p, const dvt_pk *pk, dvt_job *j, size_t i, uint32_t header[HEADER_WORDS]) {
+    std::vector<ChipTrace> traces;
+    int rc = shard_traces(p, pk, j, i, &traces);
+    if (rc) return rc;
+    Digest root;
+    if (!p->eng.commit_main_root(pk->key, traces, &root)) return fail(p, DVT_ERR_DEVICE, "%s", p->eng.err.c_str());
+    for (int k = 0; k < 8; k++) header[k] = root.d[k].canonical();
+    for (uint32_t k = 0; k < N_PUB; k++) header[8 + k] = j->shards[i].pubs[k].canonical();
+    return DVT_OK;
+}
+
+static int shard_prove(dvt_prover *p, const dvt_pk *pk, dvt_job *j, size_t i, const PermChallenges &gc, std::vector<uint32_t> *words) {
+    std::vector<ChipTrace> traces;
+    int rc = shard_traces(p, pk, j, i, &traces);
+    if (rc) return rc;
+    ShardProof sp;
+    if (!p->eng.prove_shard(pk->key, traces, j->shards[i].pubs, p->cfg, &sp, &gc)) return fail(p, DVT_ERR_DEVICE, "%s", p->eng.err.c_str());
+    WordWriter w;
+    write_shard_proof(w, sp);
+    *words = std::move(w.w);
+    return DVT_OK;
+}
+
+static std::vector<uint32_t> assemble_container(const dvt_job *j, const std::vector<std::vector<uint32_t>> &shards) {
+    WordWriter w;
+    w.u32(CORE_PROOF_MAGIC);
+    w.u32((uint32_t)shards.size());
+    w.u32((uint32_t)j->res.exit_code);
+    const auto &pv = j->res.public_values;
+    w.u32((uint32_t)pv.size());
+    for (size_t i = 0; i < pv.size(); i += 4) {
+        uint32_t v = 0;
+        for (size_t k = 0; k < 4 && i + k < pv.size(); k++) v |= (uint32_t)pv[i + k] << (8 * k);
+        w.u32(v);
+    }
+    for (auto &s : shards) {
+        w.u32((uint32_t)s.size());
+        w.w.insert(w.w.end(), s.begin(), s.end());
+    }
+    return w.w;
+}
+
+// both phases on one GPU (no lock)
+static int job_prove(dvt_prover *p, const dvt_pk *pk, dvt_job *j, uint8_t **proof, size_t *proof_len) {
+    HIP_TRY(p, hipSetDevice(p->eng.device));
+    const size_t n = j->shards.size();
+    std::vector<uint32_t> headers(n * HEADER_WORDS);
+    for (size_t i = 0; i < n; i++) {
+        int rc = shard_commit(p, pk, j, i, headers.data() + i * HEADER_WORDS);
+        if (rc) return rc;
+    }
+    PermChallenges gc = global_challenges(pk->key.vk, headers.data(), n);
+    std::vector<std::vector<uint32_t>> shards(n);
+    for (size_t i = 0; i < n; i++) {
+        int rc = shard_prove(p, pk, j, i, gc, &shards[i]);
+        if (rc) return rc;
+    }
+    (void)hipStreamSynchronize(p->eng.stream);
+    if (!proof) return DVT_OK;  // timing runs may discard the bytes
+    *proof = copy_out(assemble_container(j, shards), proof_len);
+    if (!*proof) return fail(p, DVT_ERR_DEVICE, "out of host memory");
+    return DVT_OK;
+}
 
 extern "C" {
 
@@ -457,7 +627,7 @@ int dvt_execute(const uint8_t *elf, size_t elf_len, const dvt_buf *stdin_bufs, s
         return DVT_ERR_INPUT;
     }
     rv32::ExecResult res;
-    rv32::execute(prog, collect_stdin(stdin_bufs, nbuf), false, max_cycles ? max_cycles : ~0ull, &res);
+    rv32::execute(prog, collect_stdin(stdin_bufs, nbuf), false, max_cycles ? max_cycles : ~0ull, 21, &res);
     fill_report(report, res);
     if (public_values) *public_values = dup_bytes(res.public_values, pv_len);
     if (!res.error.empty()) {
@@ -468,141 +638,6 @@ int dvt_execute(const uint8_t *elf, size_t elf_len, const dvt_buf *stdin_bufs, s
         if (err_text) *err_text = strdup("guest halted with a non-zero exit code");
         return DVT_ERR_GUEST;
     }
-    return DVT_OK;
-}
-
-static void job_release(dvt_job *j) {
-    if (!j) return;
-    if (j->d_recs) (void)hipFree(j->d_recs);
-    if (j->d_cpu) (void)hipFree(j->d_cpu);
-    for (auto &d : j->d_aux) if (d) (void)hipFree(d);
-    delete j;
-}
-
-// execute + auxiliary traces + upload (no lock: callers hold p->mu)
-static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_bufs, size_t nbuf, dvt_job **out, dvt_report *report) {
-    HIP_TRY(p, hipSetDevice(p->eng.device));
-    dvt_job *j = new dvt_job();
-    rv32::execute(pk->prog, collect_stdin(stdin_bufs, nbuf), true, SINGLE_SHARD_MAX_CYCLES, &j->res);
-    fill_report(report, j->res);
-    int rc = DVT_OK;
-    if (!j->res.error.empty()) rc = fail(p, DVT_ERR_GUEST, "guest trapped: %s", j->res.error.c_str());
-    else if (j->res.exit_code != 0) rc = fail(p, DVT_ERR_GUEST, "guest halted with exit code %d", j->res.exit_code);
-    else if (j->res.unsupported) rc = fail(p, DVT_ERR_UNSUPPORTED, "no chip for %s", j->res.unsupported_what.c_str());
-    rv32::HostTraces T;
-    std::string err;
-    if (!rc && !rv32::build_aux_host(pk->prog, j->res, pk->prep, &T, &err)) rc = fail(p, DVT_ERR_UNSUPPORTED, "%s", err.c_str());
-    if (rc) { job_release(j); return rc; }
-    const MachineDesc *m = machine_rv32();
-    j->n_recs = j->res.recs.size();
-    for (int c = 0; c < m->n_chips; c++) j->log_n[c] = T.log_n[c];
-    bool ok = hipMalloc(&j->d_recs, j->n_recs * sizeof(rv32::CycleRec)) == hipSuccess &&
-              hipMemcpy(j->d_recs, j->res.recs.data(), j->n_recs * sizeof(rv32::CycleRec), hipMemcpyHostToDevice) == hipSuccess &&
-              hipMalloc(&j->d_cpu, ((size_t)RV32_CPU_MAIN_W << j->log_n[RV32_CHIP_CPU]) * 4) == hipSuccess;
-    for (int c = 0; ok && c < m->n_chips; c++) {
-        if (c == RV32_CHIP_CPU) continue;
-        size_t words = T.main[c].size();
-        ok = hipMalloc(&j->d_aux[c], words * 4) == hipSuccess &&
-             hipMemcpy(j->d_aux[c], T.main[c].data(), words * 4, hipMemcpyHostToDevice) == hipSuccess;
-        // byte / program multiplicities stay plain integers until K0 has added the cpu rows' lookups
-        if (ok && c != RV32_CHIP_BYTE && c != RV32_CHIP_PROGRAM) ok = launch_to_internal(p->eng.stream, j->d_aux[c], words) == hipSuccess;
-    }
-    if (ok) ok = hipStreamSynchronize(p->eng.stream) == hipSuccess;
-    if (!ok) { job_release(j); return fail(p, DVT_ERR_DEVICE, "uploading the shard to the device failed"); }
-    for (auto x : T.pubs) j->pubs.push_back(Fp::from_canonical(x));
-    std::vector<rv32::CycleRec>().swap(j->res.recs);
-    *out = j;
-    return DVT_OK;
-}
-
-// K0 .. K9 on a prepared job (no lock)
-static int job_prove(dvt_prover *p, const dvt_pk *pk, dvt_job *j, uint8_t **proof, size_t *proof_len) {
-    HIP_TRY(p, hipSetDevice(p->eng.device));
-    hipStream_t st = p->eng.stream;
-    const MachineDesc *m = machine_rv32();
-    // multiplicity columns: working copies as integers, K0 adds to them, then they become field elements
-    const size_t byte_words = (size_t)rv32::N_BYTE_OPS * 65536, prog_words = (size_t)1 << j->log_n[RV32_CHIP_PROGRAM];
-    uint32_t *d_byte = nullptr, *d_prog = nullptr;
-    HIP_TRY(p, hipMalloc(&d_byte, byte_words * 4));
-    if (hipMalloc(&d_prog, prog_words * 4) != hipSuccess) { (void)hipFree(d_byte); return fail(p, DVT_ERR_DEVICE, "out of device memory"); }
-    bool ok = hipMemcpyAsync(d_byte, j->d_aux[RV32_CHIP_BYTE], byte_words * 4, hipMemcpyDeviceToDevice, st) == hipSuccess &&
-              hipMemcpyAsync(d_prog, j->d_aux[RV32_CHIP_PROGRAM], prog_words * 4, hipMemcpyDeviceToDevice, st) == hipSuccess &&
-              rv32::launch_k0_cpu_rows(st, j->d_recs, j->n_recs, pk->d_instrs, pk->d_prog_row, j->d_cpu, j->log_n[RV32_CHIP_CPU], d_byte,
-                                       d_prog) == hipSuccess &&
-              launch_to_internal(st, d_byte, byte_words) == hipSuccess && launch_to_internal(st, d_prog, prog_words) == hipSuccess;
-    ShardProof sp;
-    if (ok) {
-        std::vector<ChipTrace> traces;
-        for (int c = 0; c < m->n_chips; c++) {
-            const uint32_t *ptr = c == RV32_CHIP_CPU ? j->d_cpu : c == RV32_CHIP_BYTE ? d_byte : c == RV32_CHIP_PROGRAM ? d_prog : j->d_aux[c];
-            traces.push_back({c, j->log_n[c], ptr});
-        }
-        ok = p->eng.prove_shard(pk->key, traces, j->pubs, p->cfg, &sp);
-        if (!ok) fail(p, DVT_ERR_DEVICE, "%s", p->eng.err.c_str());
-    } else {
-        fail(p, DVT_ERR_DEVICE, "trace generation (K0) failed: %s", hipGetErrorString(hipGetLastError()));
-    }
-    (void)hipStreamSynchronize(st);
-    (void)hipFree(d_byte);
-    (void)hipFree(d_prog);
-    if (!ok) return DVT_ERR_DEVICE;
-    if (!proof) return DVT_OK;  // timing runs may discard the bytes
-    WordWriter shard;
-    write_shard_proof(shard, sp);
-    WordWriter w;
-    w.u32(CORE_PROOF_MAGIC);
-    w.u32(1);
-    w.u32((uint32_t)j->res.exit_code);
-    const auto &pv = j->res.public_values;
-    w.u32((uint32_t)pv.size());
-    for (size_t i = 0; i < pv.size(); i += 4) {
-        uint32_t v = 0;
-        for (size_t k = 0; k < 4 && i + k < pv.size(); k++) v |= (uint32_t)pv[i + k] << (8 * k);
-        w.u32(v);
-    }
-    w.u32((uint32_t)shard.w.size());
-    w.w.insert(w.w.end(), shard.w.begin(), shard.w.end());
-    *proof = copy_out(w.w, proof_len);
-    if (!*proof) return fail(p, DVT_ERR_DEVICE, "out of host memory");
-    return DVT_OK;
-}
-
-// test hook: run K0 on a prepared job and return the device-generated main traces (canonical),
-// same blob layout as dvt_rv32_debug_traces but without preprocessed columns (prep_width = 0)
-int dvt_rv32_debug_device_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *j, uint32_t **blob, size_t *blob_words) {
-    if (!p || !pk || !j || !blob || !blob_words) return fail(p, DVT_ERR_INPUT, "null argument");
-    std::lock_guard<std::mutex> lk(p->mu);
-    HIP_TRY(p, hipSetDevice(p->eng.device));
-    hipStream_t st = p->eng.stream;
-    const MachineDesc *m = machine_rv32();
-    const size_t byte_words = (size_t)rv32::N_BYTE_OPS * 65536, prog_words = (size_t)1 << j->log_n[RV32_CHIP_PROGRAM];
-    uint32_t *d_byte = nullptr, *d_prog = nullptr;
-    HIP_TRY(p, hipMalloc(&d_byte, byte_words * 4));
-    HIP_TRY(p, hipMalloc(&d_prog, prog_words * 4));
-    HIP_TRY(p, hipMemcpyAsync(d_byte, j->d_aux[RV32_CHIP_BYTE], byte_words * 4, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(p, hipMemcpyAsync(d_prog, j->d_aux[RV32_CHIP_PROGRAM], prog_words * 4, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(p, rv32::launch_k0_cpu_rows(st, j->d_recs, j->n_recs, pk->d_instrs, pk->d_prog_row, j->d_cpu, j->log_n[RV32_CHIP_CPU], d_byte, d_prog));
-    HIP_TRY(p, hipStreamSynchronize(st));
-    std::vector<uint32_t> w;
-    w.push_back((uint32_t)m->n_chips);
-    for (int c = 0; c < m->n_chips; c++) { w.push_back(c); w.push_back(j->log_n[c]); w.push_back(m->chips[c].main_w); w.push_back(0); }
-    w.push_back((uint32_t)j->pubs.size());
-    for (auto x : j->pubs) w.push_back(x.canonical());
-    for (int c = 0; c < m->n_chips; c++) {
-        size_t words = (size_t)m->chips[c].main_w << j->log_n[c];
-        std::vector<uint32_t> h(words);
-        const uint32_t *src = c == RV32_CHIP_CPU ? j->d_cpu : c == RV32_CHIP_BYTE ? d_byte : c == RV32_CHIP_PROGRAM ? d_prog : j->d_aux[c];
-        HIP_TRY(p, hipMemcpy(h.data(), src, words * 4, hipMemcpyDeviceToHost));
-        if (c != RV32_CHIP_BYTE && c != RV32_CHIP_PROGRAM)
-            for (auto &x : h) x = Fp::raw(x).canonical();
-        w.insert(w.end(), h.begin(), h.end());
-    }
-    (void)hipFree(d_byte);
-    (void)hipFree(d_prog);
-    *blob = (uint32_t *)malloc(w.size() * 4);
-    if (!*blob) return fail(p, DVT_ERR_DEVICE, "out of host memory");
-    memcpy(*blob, w.data(), w.size() * 4);
-    *blob_words = w.size();
     return DVT_OK;
 }
 
@@ -622,6 +657,51 @@ void dvt_job_free(dvt_prover *p, dvt_job *job) {
     std::lock_guard<std::mutex> lk(p->mu);
     (void)hipSetDevice(p->eng.device);
     job_release(job);
+}
+size_t dvt_rv32_job_shards(const dvt_job *job) { return job ? job->shards.size() : 0; }
+
+int dvt_rv32_commit_shard(dvt_prover *p, const dvt_pk *pk, dvt_job *job, size_t shard, uint32_t header[13]) {
+    if (!p || !pk || !job || !header || shard >= job->shards.size()) return fail(p, DVT_ERR_INPUT, "bad argument");
+    std::lock_guard<std::mutex> lk(p->mu);
+    HIP_TRY(p, hipSetDevice(p->eng.device));
+    return shard_commit(p, pk, job, shard, header);
+}
+int dvt_rv32_challenges(const uint8_t *vk, size_t vk_len, const uint32_t *headers, size_t n, uint32_t out[8]) {
+    VerifyingKey key;
+    if (!vk || !headers || !out || !n || !vk_parse(vk, vk_len, &key)) return DVT_ERR_INPUT;
+    for (size_t i = 0; i < n * HEADER_WORDS; i++)
+        if (headers[i] >= P && (i % HEADER_WORDS) < 8) return DVT_ERR_INPUT;
+    PermChallenges c = global_challenges(key, headers, n);
+    for (int k = 0; k < 4; k++) { out[k] = c.alpha.c[k].canonical(); out[4 + k] = c.beta.c[k].canonical(); }
+    return DVT_OK;
+}
+int dvt_rv32_prove_shard(dvt_prover *p, const dvt_pk *pk, dvt_job *job, size_t shard, const uint32_t challenges[8], uint8_t **proof,
+                         size_t *proof_len) {
+    if (!p || !pk || !job || !challenges || shard >= job->shards.size() || (proof && !proof_len)) return fail(p, DVT_ERR_INPUT, "bad argument");
+    std::lock_guard<std::mutex> lk(p->mu);
+    HIP_TRY(p, hipSetDevice(p->eng.device));
+    PermChallenges gc;
+    for (int k = 0; k < 4; k++) {
+        if (challenges[k] >= P || challenges[4 + k] >= P) return fail(p, DVT_ERR_INPUT, "challenge not canonical");
+        gc.alpha.c[k] = Fp::from_canonical(challenges[k]);
+        gc.beta.c[k] = Fp::from_canonical(challenges[4 + k]);
+    }
+    std::vector<uint32_t> words;
+    int rc = shard_prove(p, pk, job, shard, gc, &words);
+    if (rc || !proof) return rc;
+    *proof = copy_out(words, proof_len);
+    return *proof ? DVT_OK : fail(p, DVT_ERR_DEVICE, "out of host memory");
+}
+int dvt_rv32_assemble(const dvt_job *job, const uint8_t *const *shard_proofs, const size_t *lens, size_t n, uint8_t **proof, size_t *proof_len) {
+    if (!job || !shard_proofs || !lens || !proof || !proof_len || n != job->shards.size()) return DVT_ERR_INPUT;
+    std::vector<std::vector<uint32_t>> shards(n);
+    for (size_t i = 0; i < n; i++) {
+        if (lens[i] % 4 || !shard_proofs[i]) return DVT_ERR_INPUT;
+        shards[i].resize(lens[i] / 4);
+        memcpy(shards[i].data(), shard_proofs[i], lens[i]);
+    }
+    *proof = copy_out(assemble_container(job, shards), proof_len);
+    return *proof ? DVT_OK : DVT_ERR_DEVICE;
 }
 
 int dvt_prove_core(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_bufs, size_t nbuf, uint8_t **proof, size_t *proof_len,
@@ -657,34 +737,82 @@ int dvt_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, size_t pr
     try {
         WordReader r(words.data(), words.size());
         if (r.u32() != CORE_PROOF_MAGIC) return reject(DVT_ERR_REJECTED, "bad container magic");
-        uint32_t nshards = r.len(1 << 20);
-        if (nshards != 1) return reject(DVT_ERR_REJECTED, "multi-shard containers are not produced yet");
-        uint32_t ec = r.u32(), pvl = r.len(1 << 24);
+        const uint32_t nshards = r.len(1 << 16);
+        if (nshards == 0) return reject(DVT_ERR_REJECTED, "no shards");
+        const uint32_t ec = r.u32(), pvl = r.len(1 << 24);
         std::vector<uint8_t> pv(pvl);
         for (uint32_t i = 0; i < pvl; i += 4) {
             uint32_t v = r.u32();
             for (uint32_t k = 0; k < 4 && i + k < pvl; k++) pv[i + k] = (uint8_t)(v >> (8 * k));
         }
-        uint32_t nw = r.len(1u << 30);
-        if ((size_t)(r.end - r.p) != nw) return reject(DVT_ERR_REJECTED, "container length mismatch");
-        ShardProof sp = read_shard_proof(r);
+        std::vector<ShardProof> sps(nshards);
+        for (uint32_t i = 0; i < nshards; i++) {
+            uint32_t nw = r.len(1u << 30);
+            if ((size_t)(r.end - r.p) < nw) return reject(DVT_ERR_REJECTED, "container truncated");
+            WordReader sr(r.p, nw);
+            sps[i] = read_shard_proof(sr);
+            if (sr.p != sr.end) return reject(DVT_ERR_REJECTED, "trailing words after a shard proof");
+            r.p += nw;
+        }
         if (r.p != r.end) return reject(DVT_ERR_REJECTED, "trailing bytes after proof");
-        std::string why = verify_shard(key, sp, cfg);
-        if (!why.empty()) return reject(DVT_ERR_REJECTED, why);
-        // public values of the shard: start pc = the key's entry point, next pc = 0 (halted), exit code as claimed
-        if (sp.public_values.size() < 3) return reject(DVT_ERR_REJECTED, "missing public values");
-        if (sp.public_values[0].canonical() != key.extra[0] % P) return reject(DVT_ERR_REJECTED, "shard does not start at the entry point");
-        if (sp.public_values[1].canonical() != 0) return reject(DVT_ERR_REJECTED, "execution did not halt");
-        if (sp.public_values[2].canonical() != ec % P) return reject(DVT_ERR_REJECTED, "exit code mismatch");
-        if (sp.chips.size() != (size_t)machine_rv32()->n_chips) return reject(DVT_ERR_REJECTED, "every rv32 chip must be present");
+        // shard chaining through the public values
+        std::vector<uint32_t> headers(nshards * HEADER_WORDS);
+        for (uint32_t i = 0; i < nshards; i++) {
+            const ShardProof &sp = sps[i];
+            if (sp.public_values.size() != N_PUB) return reject(DVT_ERR_REJECTED, "wrong number of public values");
+            uint32_t pubv[N_PUB];
+            for (uint32_t k = 0; k < N_PUB; k++) pubv[k] = sp.public_values[k].canonical();
+            const bool last = i + 1 == nshards;
+            if (pubv[3] != i + 1) return reject(DVT_ERR_REJECTED, "shard index out of sequence");
+            if (pubv[4] != (last ? 1u : 0u)) return reject(DVT_ERR_REJECTED, "is_last flag does not match the shard's position");
+            if (i == 0 && pubv[0] != key.extra[0] % P) return reject(DVT_ERR_REJECTED, "first shard does not start at the entry point");
+            if (i > 0 && pubv[0] != sps[i - 1].public_values[1].canonical()) return reject(DVT_ERR_REJECTED, "shards do not chain (pc)");
+            if (last && pubv[1] != 0) return reject(DVT_ERR_REJECTED, "execution did not halt");
+            if (!last && pubv[1] == 0) return reject(DVT_ERR_REJECTED, "halt before the last shard");
+            if (last && pubv[2] != ec % P) return reject(DVT_ERR_REJECTED, "exit code mismatch");
+            // chip set: every chip in the last shard, all but mem_init in the others
+            const size_t want = last ? (size_t)machine_rv32()->n_chips : (size_t)machine_rv32()->n_chips - 1;
+            if (sp.chips.size() != want) return reject(DVT_ERR_REJECTED, "unexpected chip set in shard");
+            for (auto &c : sp.chips)
+                if (!last && c.chip_id == RV32_CHIP_MEM_INIT) return reject(DVT_ERR_REJECTED, "mem_init outside the last shard");
+            for (int k = 0; k < 8; k++) headers[i * HEADER_WORDS + k] = sp.main_root.d[k].canonical();
+            for (uint32_t k = 0; k < N_PUB; k++) headers[i * HEADER_WORDS + 8 + k] = pubv[k];
+        }
+        PermChallenges gc = global_challenges(key, headers.data(), nshards);
+        Fp4 total = Fp4::zero();
+        for (uint32_t i = 0; i < nshards; i++) {
+            Fp4 t;
+            std::string why = verify_shard(key, sps[i], cfg, &gc, &t);
+            if (!why.empty()) return reject(DVT_ERR_REJECTED, "shard " + std::to_string(i + 1) + ": " + why);
+            total += t;
+        }
+        if (total != Fp4::zero()) return reject(DVT_ERR_REJECTED, "LogUp cumulative sums do not cancel across the shards");
         if (exit_code) *exit_code = (int32_t)ec;
         if (public_values) *public_values = dup_bytes(pv, pv_len);
     } catch (const std::exception &e) { return reject(DVT_ERR_REJECTED, e.what()); }
     return DVT_OK;
 }
 
-int dvt_rv32_debug_traces(const uint8_t *elf, size_t elf_len, const dvt_buf *stdin_bufs, size_t nbuf, uint32_t **blob,
-                          size_t *blob_words, char **err_text) {
+static std::vector<uint32_t> trace_blob(const rv32::HostTraces &T, const rv32::HostPrep *prep) {
+    const MachineDesc *m = machine_rv32();
+    std::vector<uint32_t> w;
+    uint32_t present = 0;
+    for (int c = 0; c < m->n_chips; c++) present += T.present[c];
+    w.push_back(present);
+    for (int c = 0; c < m->n_chips; c++)
+        if (T.present[c]) { w.push_back(c); w.push_back(T.log_n[c]); w.push_back(m->chips[c].main_w); w.push_back(prep ? m->chips[c].prep_w : 0); }
+    w.push_back((uint32_t)T.pubs.size());
+    w.insert(w.end(), T.pubs.begin(), T.pubs.end());
+    for (int c = 0; c < m->n_chips; c++) {
+        if (!T.present[c]) continue;
+        w.insert(w.end(), T.main[c].begin(), T.main[c].end());
+        if (prep) w.insert(w.end(), prep->prep[c].begin(), prep->prep[c].end());
+    }
+    return w;
+}
+
+int dvt_rv32_debug_traces(const uint8_t *elf, size_t elf_len, const dvt_buf *stdin_bufs, size_t nbuf, uint32_t log_shard, uint32_t shard,
+                          uint32_t *n_shards, uint32_t **blob, size_t *blob_words, char **err_text) {
     if (err_text) *err_text = nullptr;
     if (!elf || !blob || !blob_words) return DVT_ERR_INPUT;
     auto bad = [&](int code, const std::string &m) { if (err_text) *err_text = strdup(m.c_str()); return code; };
@@ -694,22 +822,44 @@ int dvt_rv32_debug_traces(const uint8_t *elf, size_t elf_len, const dvt_buf *std
     rv32::HostPrep prep;
     rv32::build_prep(prog, &prep);
     rv32::ExecResult res;
-    rv32::execute(prog, collect_stdin(stdin_bufs, nbuf), true, SINGLE_SHARD_MAX_CYCLES, &res);
+    rv32::execute(prog, collect_stdin(stdin_bufs, nbuf), true, 1ull << 32, log_shard ? log_shard : 21, &res);
     if (!res.error.empty()) return bad(DVT_ERR_GUEST, res.error);
+    if (n_shards) *n_shards = (uint32_t)res.shards.size();
     rv32::HostTraces T;
-    if (!rv32::build_traces_host(prog, res, prep, &T, &err)) return bad(DVT_ERR_UNSUPPORTED, err);
-    const MachineDesc *m = machine_rv32();
-    std::vector<uint32_t> w;
-    w.push_back((uint32_t)m->n_chips);
-    for (int c = 0; c < m->n_chips; c++) { w.push_back(c); w.push_back(T.log_n[c]); w.push_back(m->chips[c].main_w); w.push_back(m->chips[c].prep_w); }
-    w.push_back((uint32_t)T.pubs.size());
-    w.insert(w.end(), T.pubs.begin(), T.pubs.end());
-    for (int c = 0; c < m->n_chips; c++) {
-        w.insert(w.end(), T.main[c].begin(), T.main[c].end());
-        w.insert(w.end(), prep.prep[c].begin(), prep.prep[c].end());
-    }
+    if (!rv32::build_traces_host(prog, res, shard, prep, &T, &err)) return bad(DVT_ERR_UNSUPPORTED, err);
+    std::vector<uint32_t> w = trace_blob(T, &prep);
     *blob = (uint32_t *)malloc(w.size() * 4);
     if (!*blob) return bad(DVT_ERR_DEVICE, "out of host memory");
+    memcpy(*blob, w.data(), w.size() * 4);
+    *blob_words = w.size();
+    return DVT_OK;
+}
+
+// test hook: run K0 on shard `shard` of a prepared job and return the device-generated main traces (canonical),
+// same blob layout as dvt_rv32_debug_traces but without preprocessed columns (prep_width = 0)
+int dvt_rv32_debug_device_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *j, size_t shard, uint32_t **blob, size_t *blob_words) {
+    if (!p || !pk || !j || !blob || !blob_words || shard >= j->shards.size()) return fail(p, DVT_ERR_INPUT, "bad argument");
+    std::lock_guard<std::mutex> lk(p->mu);
+    HIP_TRY(p, hipSetDevice(p->eng.device));
+    std::vector<ChipTrace> traces;
+    int rc = shard_traces(p, pk, j, shard, &traces);
+    if (rc) return rc;
+    HIP_TRY(p, hipStreamSynchronize(p->eng.stream));
+    const MachineDesc *m = machine_rv32();
+    rv32::HostTraces T;
+    for (int c = 0; c < 5; c++) T.present[c] = false;
+    for (auto &t : traces) {
+        size_t words = (size_t)m->chips[t.chip_id].main_w << t.log_n;
+        T.present[t.chip_id] = true;
+        T.log_n[t.chip_id] = t.log_n;
+        T.main[t.chip_id].resize(words);
+        HIP_TRY(p, hipMemcpy(T.main[t.chip_id].data(), t.d_main, words * 4, hipMemcpyDeviceToHost));
+        for (auto &x : T.main[t.chip_id]) x = Fp::raw(x).canonical();
+    }
+    for (auto x : j->shards[shard].pubs) T.pubs.push_back(x.canonical());
+    std::vector<uint32_t> w = trace_blob(T, nullptr);
+    *blob = (uint32_t *)malloc(w.size() * 4);
+    if (!*blob) return fail(p, DVT_ERR_DEVICE, "out of host memory");
     memcpy(*blob, w.data(), w.size() * 4);
     *blob_words = w.size();
     return DVT_OK;

@@ -41,8 +41,15 @@ struct ColRef {
 std::vector<ColRef> fri_columns(const MachineDesc *m, const std::vector<ChipRef> &chips, uint32_t h, uint32_t *n_two);
 void transcript_begin(Challenger &ch, const VerifyingKey &vk, const std::vector<ChipRef> &chips);
 
-// returns "" on success, otherwise the reason for rejection
-std::string verify_shard(const VerifyingKey &vk, const ShardProof &proof, const StarkConfig &cfg);
+// LogUp challenges shared by all shards of one execution (derived from every shard's main commitment);
+// nullptr = the shard samples its own (single, self-contained proof).
+struct PermChallenges {
+    Fp4 alpha, beta;
+};
+// returns "" on success, otherwise the reason for rejection.  With cumsum_total != nullptr the sum of the
+// chips' cumulative sums is returned instead of being required to vanish (the caller balances it across shards).
+std::string verify_shard(const VerifyingKey &vk, const ShardProof &proof, const StarkConfig &cfg,
+                         const PermChallenges *global = nullptr, Fp4 *cumsum_total = nullptr);
 
 #if defined(__HIPCC__)
 struct Arena {
@@ -110,7 +117,9 @@ class Engine {
                ProvingKey *pk);
     void free_key(ProvingKey *pk);
     bool prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &traces, const std::vector<Fp> &pubs,
-                     const StarkConfig &cfg, ShardProof *out);
+                     const StarkConfig &cfg, ShardProof *out, const PermChallenges *global = nullptr);
+    // phase 1 of a multi-shard proof: K1-K3 of the main traces only -> main_root (nothing is kept)
+    bool commit_main_root(const ProvingKey &pk, const std::vector<ChipTrace> &traces, Digest *root);
 
     Arena arena;
 

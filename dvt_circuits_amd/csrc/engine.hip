@@ -260,8 +260,43 @@ struct EventTimer {
 };
 }  // namespace
 
+bool Engine::commit_main_root(const ProvingKey &pk, const std::vector<ChipTrace> &traces, Digest *root) {
+    HIPCHK(hipSetDevice(device));
+    const MachineDesc *m = pk.vk.machine;
+    arena.reset();
+    size_t need = 0, max_mat_words = 0;
+    uint32_t max_log_n = 0;
+    for (auto &t : traces) {
+        if (t.chip_id < 0 || t.chip_id >= m->n_chips || t.log_n > 22 || !t.d_main) return fail("commit: bad chip trace");
+        size_t words = (size_t)m->chips[t.chip_id].main_w << t.log_n;
+        need += words * 8 + 4096;
+        max_mat_words = std::max(max_mat_words, words);
+        max_log_n = std::max(max_log_n, t.log_n);
+    }
+    need += max_mat_words * 4 + (((size_t)4 << max_log_n)) * 32 + (1u << 20);
+    if (arena.cap < need) HIPCHK(arena.reserve(need + need / 8));
+    uint32_t *d_scratch = arena.alloc<uint32_t>(max_mat_words);
+    if (!d_scratch) return fail("commit: device arena exhausted");
+    std::vector<DevMat> mats;
+    for (auto &t : traces) {
+        const ChipDesc &d = m->chips[t.chip_id];
+        uint32_t *lde = arena.alloc<uint32_t>(((size_t)d.main_w << t.log_n) * 2);
+        if (!lde) return fail("commit: device arena exhausted");
+        HIPCHK(launch_coset_lde(stream, tabs, const_cast<uint32_t *>(t.d_main), d_scratch, lde, d.main_w, t.log_n, 0));
+        mats.push_back({lde, (uint32_t)d.main_w, t.log_n + 1});
+    }
+    const uint32_t hmax = max_log_n + 1;
+    uint32_t *tree = arena.alloc<uint32_t>((((size_t)2 << hmax) - 1) * 8);
+    if (!tree) return fail("commit: device arena exhausted");
+    if (!commit_tree(mats, tree)) return false;
+    uint32_t rootw[8];
+    if (!download(rootw, tree + ((((size_t)2 << hmax) - 1) * 8) - 8, 32)) return false;
+    for (int i = 0; i < 8; i++) root->d[i] = Fp::raw(rootw[i]);
+    return true;
+}
+
 bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &traces, const std::vector<Fp> &pubs,
-                         const StarkConfig &cfg, ShardProof *out) {
+                         const StarkConfig &cfg, ShardProof *out, const PermChallenges *global) {
     HIPCHK(hipSetDevice(device));
     const MachineDesc *m = pk.vk.machine;
     arena.reset();
@@ -379,7 +414,16 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
     times.commit_main = tm.stop();
 
     // ---- 2. permutation trace (K4) + LDE + commit
-    Fp4 perm_alpha = ch.sample_ext(), beta = ch.sample_ext();
+    Fp4 perm_alpha, beta;
+    if (global) {  // common to all shards of the execution; bound into this shard's transcript
+        perm_alpha = global->alpha;
+        beta = global->beta;
+        ch.observe(perm_alpha);
+        ch.observe(beta);
+    } else {
+        perm_alpha = ch.sample_ext();
+        beta = ch.sample_ext();
+    }
     int max_arity = 1, max_folded = 1;
     for (int i = 0; i < m->n_chips; i++) {
         max_arity = std::max(max_arity, m->chips[i].max_arity);

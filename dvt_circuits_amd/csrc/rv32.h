@@ -46,17 +46,25 @@ struct Program {
     std::vector<std::pair<uint32_t, uint32_t>> image;     // (byte address, word), sorted, word aligned
 };
 
-// One retired instruction, compact (what the host uploads for K0): 12 words.
+// One retired instruction, compact (what the host uploads for K0): 16 words.
+// Timestamps are (shard, clk) pairs: *_sh = shard of the previous access, *_ts = its clk.
 struct CycleRec {
     uint32_t idx;      // instruction index in Program::instrs
     uint32_t a, b, c;  // rd value written / rs1 value / rs2-or-immediate value
     uint32_t pa_prev, pa_ts, pb_ts, pc_ts;
     uint32_t next_pc;
     uint32_t m_val, m_prev, m_ts;
+    uint32_t pa_sh, pb_sh, pc_sh, m_sh;
 };
 
 struct MemInitRow {
-    uint32_t addr, v, f, fts, is_img;
+    uint32_t addr, v, f, fts, fsh, is_img;
+};
+
+// One shard = up to 2^log_shard consecutive cycles; shards are numbered from 1.
+struct ShardRec {
+    uint32_t index = 0, start_pc = 0, next_pc = 0;
+    std::vector<CycleRec> recs;
 };
 
 struct ExecResult {
@@ -66,20 +74,21 @@ struct ExecResult {
     bool unsupported = false;   // retired an instruction the prover has no chip for
     std::string unsupported_what;
     std::vector<uint8_t> public_values, stdout_bytes;
-    std::vector<CycleRec> recs;          // filled only when tracing
-    std::vector<MemInitRow> mem_rows;    // sorted by address, filled only when tracing
+    std::vector<ShardRec> shards;        // filled only when tracing
+    std::vector<MemInitRow> mem_rows;    // sorted by address, filled only when tracing (part of the LAST shard)
     std::string error;                   // non-empty: the guest trapped (bad access, bad pc, ...)
 };
 
 bool load_elf(const uint8_t *elf, size_t n, Program *out, std::string *err);
-// stdin: list of buffers.  trace = keep per-cycle records.  max_cycles bounds the run.
+// stdin: list of buffers.  trace = keep per-cycle records, cut into shards of 2^log_shard cycles.
+// max_cycles bounds the run.
 void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin_bufs, bool trace, uint64_t max_cycles,
-             ExecResult *res);
+             uint32_t log_shard, ExecResult *res);
 
 // ---- trace generation (K0) ---------------------------------------------------
 // Sink interface used by fill_cpu_row:  put(col, canonical value);  byte(op_index, table_row);  prog(idx)
 template <class Sink>
-DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, Sink &s) {
+DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint32_t shard, Sink &s) {
     const uint32_t fl = in.flags;
     auto F = [&](uint32_t bit) -> uint32_t { return (fl >> bit) & 1u; };
     auto B = [](uint32_t w, int i) -> uint32_t { return (w >> (8 * i)) & 0xffu; };
@@ -104,19 +113,24 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, Sink 
     s.prog(r.idx);
     // register ports
     uint32_t pb_hi = 0, pc_hi = 0, pa_hi = 0, m_hi = 0;
+    // (shard', clk') < (shard, clk): same shard -> clk difference, earlier shard -> shard difference
+    auto gap = [&](uint32_t prev_sh, uint32_t prev_ts, uint32_t ts) -> uint32_t { return prev_sh == shard ? ts - prev_ts - 1 : shard - prev_sh - 1; };
     if (F(F_RS2_EN)) {
-        uint32_t d = clk - r.pc_ts - 1;
-        s.put(RV32_CPU_pc_ts, r.pc_ts); s.put(RV32_CPU_pc_lo, d & 0xffff); pc_hi = d >> 16;
+        uint32_t d = gap(r.pc_sh, r.pc_ts, clk);
+        s.put(RV32_CPU_pc_ts, r.pc_ts); s.put(RV32_CPU_pc_sh, r.pc_sh); s.put(RV32_CPU_pc_same, r.pc_sh == shard);
+        s.put(RV32_CPU_pc_lo, d & 0xffff); pc_hi = d >> 16;
         s.byte(B_U16 - 1, d & 0xffff);
     }
     if (F(F_RS1_EN)) {
-        uint32_t d = clk + 1 - r.pb_ts - 1;
-        s.put(RV32_CPU_pb_ts, r.pb_ts); s.put(RV32_CPU_pb_lo, d & 0xffff); pb_hi = d >> 16;
+        uint32_t d = gap(r.pb_sh, r.pb_ts, clk + 1);
+        s.put(RV32_CPU_pb_ts, r.pb_ts); s.put(RV32_CPU_pb_sh, r.pb_sh); s.put(RV32_CPU_pb_same, r.pb_sh == shard);
+        s.put(RV32_CPU_pb_lo, d & 0xffff); pb_hi = d >> 16;
         s.byte(B_U16 - 1, d & 0xffff);
     }
     if (F(F_RD_EN)) {
-        uint32_t d = clk + 3 - r.pa_ts - 1;
-        s.put(RV32_CPU_pa_ts, r.pa_ts); s.put(RV32_CPU_pa_lo, d & 0xffff); pa_hi = d >> 16;
+        uint32_t d = gap(r.pa_sh, r.pa_ts, clk + 3);
+        s.put(RV32_CPU_pa_ts, r.pa_ts); s.put(RV32_CPU_pa_sh, r.pa_sh); s.put(RV32_CPU_pa_same, r.pa_sh == shard);
+        s.put(RV32_CPU_pa_lo, d & 0xffff); pa_hi = d >> 16;
         s.byte(B_U16 - 1, d & 0xffff);
     }
     s.put(RV32_CPU_pb_hi, pb_hi); s.put(RV32_CPU_pc_hi, pc_hi); s.put(RV32_CPU_pa_hi, pa_hi);
@@ -186,9 +200,9 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, Sink 
             s.put(U + 8, sum & 1);
         } else {
             for (int i = 0; i < 4; i++) { s.put(U + 8 + i, B(r.m_val, i)); s.put(U + 12 + i, B(r.m_prev, i)); }
-            uint32_t d = clk + 2 - r.m_ts - 1;
+            uint32_t d = gap(r.m_sh, r.m_ts, clk + 2);
             s.put(U + 16, r.m_ts); s.put(U + 17, d & 0xffff); m_hi = d >> 16;
-            s.put(U + 18, m_hi);
+            s.put(U + 18, m_hi); s.put(U + 19, r.m_sh); s.put(U + 20, r.m_sh == shard);
             s.byte(B_U16 - 1, d & 0xffff);
             s.byte(B_AND - 1, (B(sum, 0) << 8) | 3);
         }
@@ -206,10 +220,12 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, Sink 
 }
 
 // Host-side trace bundle of one shard (canonical, column-major), for the debug C-ABI and tests.
+// present[c] = chip c is part of this shard (mem_init only in the last one).
 struct HostTraces {
     uint32_t log_n[5];
+    bool present[5];
     std::vector<uint32_t> main[5];
-    std::vector<uint32_t> pubs;
+    std::vector<uint32_t> pubs;   // start_pc, next_pc, exit_code, shard, is_last
 };
 // preprocessed traces (program, byte, mem_image) for setup
 struct HostPrep {
@@ -217,17 +233,17 @@ struct HostPrep {
     std::vector<uint32_t> prep[5];
 };
 void build_prep(const Program &prog, HostPrep *out);
-bool build_traces_host(const Program &prog, const ExecResult &res, const HostPrep &prep, HostTraces *out, std::string *err);
+bool build_traces_host(const Program &prog, const ExecResult &res, size_t shard_pos, const HostPrep &prep, HostTraces *out, std::string *err);
 // Everything of a shard except the cpu trace and the lookups the cpu rows make: mem_init rows, the
 // byte-table multiplicities caused by mem_init, zeroed program/mem_image columns, public values.
 // The device path (K0) adds the cpu chip and its lookup counts on top.
-bool build_aux_host(const Program &prog, const ExecResult &res, const HostPrep &prep, HostTraces *out, std::string *err);
+bool build_aux_host(const Program &prog, const ExecResult &res, size_t shard_pos, const HostPrep &prep, HostTraces *out, std::string *err);
 // instruction index -> row of the program table (provable instructions only; others map to row 0 and never occur)
 std::vector<uint32_t> program_row_map(const Program &prog);
 
 #if defined(__HIPCC__)
-hipError_t launch_k0_cpu_rows(hipStream_t st, const CycleRec *d_recs, size_t n_recs, const Instr *d_instrs, const uint32_t *d_prog_row,
-                              uint32_t *d_cpu, uint32_t log_n, uint32_t *d_byte_mult, uint32_t *d_prog_mult);
+hipError_t launch_k0_cpu_rows(hipStream_t st, const CycleRec *d_recs, size_t n_recs, uint32_t shard, const Instr *d_instrs,
+                              const uint32_t *d_prog_row, uint32_t *d_cpu, uint32_t log_n, uint32_t *d_byte_mult, uint32_t *d_prog_mult);
 #endif
 
 }  // namespace rv32

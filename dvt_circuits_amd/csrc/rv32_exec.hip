@@ -123,38 +123,50 @@ bool load_elf(const uint8_t *elf, size_t n, Program *out, std::string *err) {
 
 // ------------------------------------------------------------------ interpreter
 namespace {
-struct Cell { uint32_t val, ts; uint8_t touched, img; uint32_t init; };
+struct Cell { uint32_t val, ts, sh; uint8_t touched, img; uint32_t init; };
 struct Memory {
     static constexpr uint32_t PAGE_BITS = 10;
     std::unordered_map<uint32_t, std::vector<Cell>> pages;
-    Cell &at(uint32_t addr) {  // addr: word-aligned byte address (or register index 0..31 scaled by caller)
+    Cell &at(uint32_t addr) {  // addr: word-aligned byte address
         uint32_t w = addr >> 2, pg = w >> PAGE_BITS;
         auto it = pages.find(pg);
-        if (it == pages.end()) it = pages.emplace(pg, std::vector<Cell>(1u << PAGE_BITS, Cell{0, 0, 0, 0, 0})).first;
+        if (it == pages.end()) it = pages.emplace(pg, std::vector<Cell>(1u << PAGE_BITS, Cell{0, 0, 0, 0, 0, 0})).first;
         return it->second[w & ((1u << PAGE_BITS) - 1)];
     }
 };
 }  // namespace
 
 void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin_bufs, bool trace, uint64_t max_cycles,
-             ExecResult *res) {
+             uint32_t log_shard, ExecResult *res) {
     ExecResult &R = *res;
     R = ExecResult();
     Memory mem;  // guest memory, keyed by byte address; registers are kept separately (addresses 0..31 of the AIR)
     Cell regs[32];
-    for (auto &c : regs) c = Cell{0, 0, 0, 0, 0};
+    for (auto &c : regs) c = Cell{0, 0, 0, 0, 0, 0};
     for (auto &kv : prog.image)
         if (kv.first >= 32) { Cell &c = mem.at(kv.first); c.val = c.init = kv.second; c.img = 1; }
     size_t next_input = 0;
     uint32_t pc = prog.entry;
     const size_t ninstr = prog.instrs.size();
+    const uint64_t shard_cycles = (uint64_t)1 << log_shard;
+    uint32_t shard = 1;   // current shard index (timestamps are (shard, clk))
+    uint32_t in_shard = 0;  // instructions retired in the current shard
+    if (trace) { R.shards.emplace_back(); R.shards.back().index = 1; R.shards.back().start_pc = pc; }
     auto trap = [&](const std::string &m) { R.error = m + " at pc 0x" + [&] { char b[16]; snprintf(b, sizeof b, "%x", pc); return std::string(b); }(); };
     while (R.cycles < max_cycles) {
         if (pc < prog.text_base || pc % 4 || (pc - prog.text_base) / 4 >= ninstr) { trap("pc outside text"); return; }
+        if (trace && in_shard == shard_cycles) {  // cut a shard
+            R.shards.back().next_pc = pc;
+            shard++;
+            in_shard = 0;
+            R.shards.emplace_back();
+            R.shards.back().index = shard;
+            R.shards.back().start_pc = pc;
+        }
         const uint32_t idx = (pc - prog.text_base) / 4;
         const Instr &in = prog.instrs[idx];
         const uint32_t w = in.raw, fl = in.flags;
-        const uint32_t clk = 4 * (uint32_t)((trace ? R.recs.size() : 0) + 1);
+        const uint32_t clk = 4 * (in_shard + 1);
         CycleRec rec{};
         rec.idx = idx;
         uint32_t next_pc = pc + 4, a = 0, b = 0, c = 0;
@@ -206,12 +218,13 @@ void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin
             if (wr && rd) regs[rd].val = out;
             pc = next_pc;
             R.cycles++;
+            in_shard++;
             continue;
         }
         // ---- provable instruction: accesses in port order c (rs2), b (rs1), memory, a (rd)
-        if (fl & FL(F_RS2_EN)) { Cell &r2 = regs[in.rs2]; c = r2.val; rec.pc_ts = r2.ts; r2.ts = clk; r2.touched = 1; }
+        if (fl & FL(F_RS2_EN)) { Cell &r2 = regs[in.rs2]; c = r2.val; rec.pc_ts = r2.ts; rec.pc_sh = r2.sh; r2.ts = clk; r2.sh = shard; r2.touched = 1; }
         if (fl & FL(F_IMM_C)) c = in.imm;
-        if (fl & FL(F_RS1_EN)) { Cell &r1 = regs[in.rs1]; b = r1.val; rec.pb_ts = r1.ts; r1.ts = clk + 1; r1.touched = 1; }
+        if (fl & FL(F_RS1_EN)) { Cell &r1 = regs[in.rs1]; b = r1.val; rec.pb_ts = r1.ts; rec.pb_sh = r1.sh; r1.ts = clk + 1; r1.sh = shard; r1.touched = 1; }
         if (fl & (FL(F_ADD))) a = b + c;
         else if (fl & FL(F_SUB)) a = b - c;
         else if (fl & FL(F_AND)) a = b & c;
@@ -240,9 +253,11 @@ void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin
             if (!cell.touched) { cell.touched = 1; cell.init = cell.val; }
             rec.m_prev = cell.val;
             rec.m_ts = cell.ts;
+            rec.m_sh = cell.sh;
             if (fl & FL(F_SW)) cell.val = c; else a = cell.val;
             rec.m_val = cell.val;
             cell.ts = clk + 2;
+            cell.sh = shard;
         } else if (fl & FL(F_ECALL)) {
             // b = t0 (id), c = a0
             uint32_t a1 = regs[11].val, a2 = regs[12].val;
@@ -267,7 +282,7 @@ void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin
                 if (c % 4 || c < 32 || (uint64_t)c + a1 > ADDR_LIMIT) { trap("HINT_READ pointer misaligned or out of range"); return; }
                 for (uint32_t k = 0; k < a1; k += 4) {
                     Cell &cell = mem.at(c + k);
-                    if (cell.touched || cell.ts || cell.img) { trap("HINT_READ into the program image or into memory that was already accessed"); return; }
+                    if (cell.touched || cell.sh || cell.img) { trap("HINT_READ into the program image or into memory that was already accessed"); return; }
                     uint32_t wv = 0;
                     for (uint32_t q = 0; q < 4 && k + q < a1; q++) wv |= (uint32_t)buf[k + q] << (8 * q);
                     cell.val = wv;
@@ -277,20 +292,22 @@ void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin
             default: trap("unknown syscall"); return;
             }
         }
-        if (fl & FL(F_RD_EN)) { Cell &rdc = regs[in.rd]; rec.pa_prev = rdc.val; rec.pa_ts = rdc.ts; rdc.val = a; rdc.ts = clk + 3; rdc.touched = 1; }
+        if (fl & FL(F_RD_EN)) { Cell &rdc = regs[in.rd]; rec.pa_prev = rdc.val; rec.pa_ts = rdc.ts; rec.pa_sh = rdc.sh; rdc.val = a; rdc.ts = clk + 3; rdc.sh = shard; rdc.touched = 1; }
         rec.a = a; rec.b = b; rec.c = c; rec.next_pc = next_pc;
-        if (trace) R.recs.push_back(rec);
+        if (trace) R.shards.back().recs.push_back(rec);
         R.cycles++;
+        in_shard++;
         pc = next_pc;
         if (R.halted) break;
     }
     if (!R.halted && R.error.empty()) R.error = "cycle limit reached before HALT";
     if (trace) {
+        R.shards.back().next_pc = pc;  // 0 after HALT
         // one mem_init row per image word and per touched non-image word, sorted by address
         std::map<uint32_t, MemInitRow> rows;
         for (auto &kv : prog.image) {
-            MemInitRow r{kv.first, kv.second, kv.second, 0, 1};
-            if (kv.first < 32) { r.f = regs[kv.first].val; r.fts = regs[kv.first].ts; }
+            MemInitRow r{kv.first, kv.second, kv.second, 0, 0, 1};
+            if (kv.first < 32) { r.f = regs[kv.first].val; r.fts = regs[kv.first].ts; r.fsh = regs[kv.first].sh; }
             rows[kv.first] = r;
         }
         for (auto &pg : mem.pages)
@@ -298,8 +315,9 @@ void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin
                 const Cell &cell = pg.second[k];
                 uint32_t addr = ((pg.first << Memory::PAGE_BITS) | k) << 2;
                 auto it = rows.find(addr);
-                if (it != rows.end()) { it->second.f = cell.val; it->second.fts = cell.ts; if (!cell.touched) it->second.f = it->second.v; }
-                else if (cell.touched) rows[addr] = MemInitRow{addr, cell.init, cell.val, cell.ts, 0};
+                if (it != rows.end()) {
+                    if (cell.touched) { it->second.f = cell.val; it->second.fts = cell.ts; it->second.fsh = cell.sh; }
+                } else if (cell.touched) rows[addr] = MemInitRow{addr, cell.init, cell.val, cell.ts, cell.sh, 0};
             }
         for (auto &kv : rows) R.mem_rows.push_back(kv.second);
     }
@@ -365,28 +383,6 @@ struct HostSink {
 };
 }  // namespace
 
-bool build_traces_host(const Program &prog, const ExecResult &res, const HostPrep &prep, HostTraces *out, std::string *err) {
-    HostTraces &T = *out;
-    if (res.recs.empty()) { if (err) *err = "no cycles to prove"; return false; }
-    if (res.unsupported) { if (err) *err = "unsupported " + res.unsupported_what; return false; }
-    const uint32_t lc = ceil_log2(res.recs.size());
-    if (lc > 22) { if (err) *err = "shard too long (> 2^22 cycles); multi-shard proving lands next"; return false; }
-    const size_t nc = (size_t)1 << lc;
-    if (!build_aux_host(prog, res, prep, out, err)) return false;
-    T.main[RV32_CHIP_CPU].assign((size_t)RV32_CPU_MAIN_W * nc, 0);
-    std::vector<uint32_t> prog_idx_mult(prog.instrs.size(), 0);
-    HostSink sink{T.main[RV32_CHIP_CPU].data(), nc, 0, T.main[RV32_CHIP_BYTE].data(), prog_idx_mult.data()};
-    for (size_t r = 0; r < res.recs.size(); r++) {
-        sink.row = r;
-        fill_cpu_row(res.recs[r], prog.instrs[res.recs[r].idx], (uint32_t)r, sink);
-    }
-    // program multiplicities follow the preprocessed row order (provable instructions only)
-    std::vector<uint32_t> rowmap = program_row_map(prog);
-    for (size_t i = 0; i < prog.instrs.size(); i++)
-        if (prog.instrs[i].supported) T.main[RV32_CHIP_PROGRAM][rowmap[i]] = prog_idx_mult[i];
-    return true;
-}
-
 std::vector<uint32_t> program_row_map(const Program &prog) {
     std::vector<uint32_t> m(prog.instrs.size(), 0);
     uint32_t r = 0;
@@ -395,41 +391,47 @@ std::vector<uint32_t> program_row_map(const Program &prog) {
     return m;
 }
 
-bool build_aux_host(const Program &prog, const ExecResult &res, const HostPrep &prep, HostTraces *out, std::string *err) {
+bool build_aux_host(const Program &prog, const ExecResult &res, size_t shard_pos, const HostPrep &prep, HostTraces *out, std::string *err) {
     HostTraces &T = *out;
-    if (res.recs.empty()) { if (err) *err = "no cycles to prove"; return false; }
+    if (shard_pos >= res.shards.size() || res.shards[shard_pos].recs.empty()) { if (err) *err = "no cycles to prove"; return false; }
     if (res.unsupported) { if (err) *err = "unsupported " + res.unsupported_what; return false; }
-    const uint32_t lc = ceil_log2(res.recs.size());
-    if (lc > 22) { if (err) *err = "shard too long (> 2^22 cycles); multi-shard proving lands next"; return false; }
+    const ShardRec &S = res.shards[shard_pos];
+    const bool last = shard_pos + 1 == res.shards.size();
+    const uint32_t lc = ceil_log2(S.recs.size());
+    if (lc > 22) { if (err) *err = "shard longer than 2^22 cycles"; return false; }
+    for (int c = 0; c < 5; c++) { T.present[c] = true; T.main[c].clear(); }
     T.log_n[RV32_CHIP_CPU] = lc;
-    T.main[RV32_CHIP_CPU].clear();
     std::vector<uint32_t> byte_mult((size_t)N_BYTE_OPS * 65536, 0);
     HostSink sink{nullptr, 0, 0, byte_mult.data(), nullptr};
-    // mem_init
-    const uint32_t lm = ceil_log2(res.mem_rows.size());
-    const size_t nm = (size_t)1 << lm;
-    T.log_n[RV32_CHIP_MEM_INIT] = lm;
-    auto &M = T.main[RV32_CHIP_MEM_INIT];
-    M.assign((size_t)RV32_MEM_INIT_MAIN_W * nm, 0);
-    uint32_t prev_addr = 0;
-    for (size_t r = 0; r < res.mem_rows.size(); r++) {
-        const MemInitRow &m = res.mem_rows[r];
-        auto put = [&](int col, uint32_t v) { M[(size_t)col * nm + r] = v; };
-        put(RV32_MEM_INIT_addr, m.addr); put(RV32_MEM_INIT_fts, m.fts); put(RV32_MEM_INIT_is_img, m.is_img); put(RV32_MEM_INIT_is_real, 1);
-        uint32_t d = r ? m.addr - prev_addr - 1 : 0;
-        for (int i = 0; i < 4; i++) {
-            put(RV32_MEM_INIT_v_0 + i, (m.v >> (8 * i)) & 0xff);
-            put(RV32_MEM_INIT_f_0 + i, (m.f >> (8 * i)) & 0xff);
-            put(RV32_MEM_INIT_d_0 + i, (d >> (8 * i)) & 0xff);
+    T.present[RV32_CHIP_MEM_INIT] = last;
+    T.log_n[RV32_CHIP_MEM_INIT] = 0;
+    if (last) {
+        const uint32_t lm = ceil_log2(res.mem_rows.size());
+        const size_t nm = (size_t)1 << lm;
+        T.log_n[RV32_CHIP_MEM_INIT] = lm;
+        auto &M = T.main[RV32_CHIP_MEM_INIT];
+        M.assign((size_t)RV32_MEM_INIT_MAIN_W * nm, 0);
+        uint32_t prev_addr = 0;
+        for (size_t r = 0; r < res.mem_rows.size(); r++) {
+            const MemInitRow &m = res.mem_rows[r];
+            auto put = [&](int col, uint32_t v) { M[(size_t)col * nm + r] = v; };
+            put(RV32_MEM_INIT_addr, m.addr); put(RV32_MEM_INIT_fts, m.fts); put(RV32_MEM_INIT_fsh, m.fsh);
+            put(RV32_MEM_INIT_is_img, m.is_img); put(RV32_MEM_INIT_is_real, 1);
+            uint32_t d = r ? m.addr - prev_addr - 1 : 0;
+            for (int i = 0; i < 4; i++) {
+                put(RV32_MEM_INIT_v_0 + i, (m.v >> (8 * i)) & 0xff);
+                put(RV32_MEM_INIT_f_0 + i, (m.f >> (8 * i)) & 0xff);
+                put(RV32_MEM_INIT_d_0 + i, (d >> (8 * i)) & 0xff);
+            }
+            sink.byte(B_RANGE - 1, ((d & 0xff) << 8) | ((d >> 8) & 0xff));
+            sink.byte(B_RANGE - 1, (((d >> 16) & 0xff) << 8) | (d >> 24));
+            sink.byte(B_LTU - 1, ((d >> 24) << 8) | 0x40);
+            if (!m.is_img) {
+                sink.byte(B_RANGE - 1, ((m.v & 0xff) << 8) | ((m.v >> 8) & 0xff));
+                sink.byte(B_RANGE - 1, (((m.v >> 16) & 0xff) << 8) | (m.v >> 24));
+            }
+            prev_addr = m.addr;
         }
-        sink.byte(B_RANGE - 1, ((d & 0xff) << 8) | ((d >> 8) & 0xff));
-        sink.byte(B_RANGE - 1, (((d >> 16) & 0xff) << 8) | (d >> 24));
-        sink.byte(B_LTU - 1, ((d >> 24) << 8) | 0x40);
-        if (!m.is_img) {
-            sink.byte(B_RANGE - 1, ((m.v & 0xff) << 8) | ((m.v >> 8) & 0xff));
-            sink.byte(B_RANGE - 1, (((m.v >> 16) & 0xff) << 8) | (m.v >> 24));
-        }
-        prev_addr = m.addr;
     }
     const uint32_t lp = prep.log_n[RV32_CHIP_PROGRAM];
     T.log_n[RV32_CHIP_PROGRAM] = lp;
@@ -438,7 +440,26 @@ bool build_aux_host(const Program &prog, const ExecResult &res, const HostPrep &
     T.main[RV32_CHIP_BYTE] = byte_mult;  // [7][65536] already column-major in op order
     T.log_n[RV32_CHIP_MEM_IMAGE] = prep.log_n[RV32_CHIP_MEM_IMAGE];
     T.main[RV32_CHIP_MEM_IMAGE].assign((size_t)1 << T.log_n[RV32_CHIP_MEM_IMAGE], 0);
-    T.pubs = {prog.entry % P, res.recs.back().next_pc % P, (uint32_t)res.exit_code % P};
+    T.pubs = {S.start_pc % P, S.next_pc % P, last ? (uint32_t)res.exit_code % P : 0u, S.index, last ? 1u : 0u};
+    return true;
+}
+
+bool build_traces_host(const Program &prog, const ExecResult &res, size_t shard_pos, const HostPrep &prep, HostTraces *out, std::string *err) {
+    HostTraces &T = *out;
+    if (!build_aux_host(prog, res, shard_pos, prep, out, err)) return false;
+    const ShardRec &S = res.shards[shard_pos];
+    const size_t nc = (size_t)1 << T.log_n[RV32_CHIP_CPU];
+    T.main[RV32_CHIP_CPU].assign((size_t)RV32_CPU_MAIN_W * nc, 0);
+    std::vector<uint32_t> prog_idx_mult(prog.instrs.size(), 0);
+    HostSink sink{T.main[RV32_CHIP_CPU].data(), nc, 0, T.main[RV32_CHIP_BYTE].data(), prog_idx_mult.data()};
+    for (size_t r = 0; r < S.recs.size(); r++) {
+        sink.row = r;
+        fill_cpu_row(S.recs[r], prog.instrs[S.recs[r].idx], (uint32_t)r, S.index, sink);
+    }
+    // program multiplicities follow the preprocessed row order (provable instructions only)
+    std::vector<uint32_t> rowmap = program_row_map(prog);
+    for (size_t i = 0; i < prog.instrs.size(); i++)
+        if (prog.instrs[i].supported) T.main[RV32_CHIP_PROGRAM][rowmap[i]] = prog_idx_mult[i];
     return true;
 }
 

@@ -67,7 +67,8 @@ Fp4 ext_from_flat(const Fp4 *p) {  // sum_k x^k * p[k]
 
 }  // namespace
 
-std::string verify_shard(const VerifyingKey &vk, const ShardProof &pf, const StarkConfig &cfg) {
+std::string verify_shard(const VerifyingKey &vk, const ShardProof &pf, const StarkConfig &cfg, const PermChallenges *global,
+                         Fp4 *cumsum_total) {
     const MachineDesc *m = vk.machine;
     if (!m) return "no machine";
     if (pf.chips.empty()) return "no chips";
@@ -109,7 +110,16 @@ std::string verify_shard(const VerifyingKey &vk, const ShardProof &pf, const Sta
     ch.observe(pf.main_root);
     ch.observe_u32((uint32_t)pf.public_values.size());
     for (auto x : pf.public_values) ch.observe(x);
-    Fp4 perm_alpha = ch.sample_ext(), beta = ch.sample_ext();
+    Fp4 perm_alpha, beta;
+    if (global) {
+        perm_alpha = global->alpha;
+        beta = global->beta;
+        ch.observe(perm_alpha);
+        ch.observe(beta);
+    } else {
+        perm_alpha = ch.sample_ext();
+        beta = ch.sample_ext();
+    }
     ch.observe(pf.perm_root);
     Fp4 total = Fp4::zero();
     for (auto &o : pf.chips) {
@@ -118,7 +128,8 @@ std::string verify_shard(const VerifyingKey &vk, const ShardProof &pf, const Sta
         ch.observe(o.cumsum);
         total += o.cumsum;
     }
-    if (total != Fp4::zero()) return "LogUp cumulative sums do not cancel";
+    if (cumsum_total) *cumsum_total = total;
+    else if (total != Fp4::zero()) return "LogUp cumulative sums do not cancel";
     Fp4 alpha = ch.sample_ext();
     ch.observe(pf.quot_root);
     Fp4 zeta = ch.sample_ext();

@@ -149,28 +149,43 @@ int dvt_execute(const uint8_t *elf, size_t elf_len, const dvt_buf *stdin_bufs, s
  * (src/main.rs:472-474) would write. */
 int dvt_prove_core(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_bufs, size_t nbuf, uint8_t **proof,
                    size_t *proof_len, dvt_report *report);
-/* The two halves of dvt_prove_core, split so that callers (and bench.py) can keep a
- * shard resident in HBM: prepare = host execution + upload of the compact per-cycle
- * records and the small auxiliary traces; prove_job = K0 (trace expansion) .. K9 on
- * the GPU.  proof may be NULL to discard the bytes.  A job can be proven repeatedly. */
+/* dvt_prove_core in pieces, so that callers (and bench.py) can keep an execution resident in HBM and
+ * spread its shards over several GPUs.  An execution is cut into shards of 2^log_shard_size cycles
+ * (cfg "log_shard_size", default 21).  All shards are proven with COMMON LogUp challenges derived
+ * from every shard's 13-word header (main-trace Merkle root + 5 public values), which is the one
+ * exchange step of the path (an all-gather of 52 bytes per shard):
+ *   prepare        host execution + upload of the compact per-cycle records and auxiliary traces
+ *   commit_shard   phase 1 of shard i: K0 + K1..K3 of the main traces -> header
+ *   challenges     host-only: the common challenges from ALL headers (in shard order)
+ *   prove_shard    phase 2 of shard i: K0..K9 with those challenges -> shard proof bytes
+ *   assemble       container (what proof.save would write) from the shard proofs, in order
+ * dvt_rv32_prove_job runs everything on the handle's GPU; proof may be NULL to discard the bytes. */
 typedef struct dvt_job dvt_job;
 int dvt_rv32_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_bufs, size_t nbuf, dvt_job **job,
                      dvt_report *report);
 int dvt_rv32_prove_job(dvt_prover *p, const dvt_pk *pk, dvt_job *job, uint8_t **proof, size_t *proof_len);
 void dvt_job_free(dvt_prover *p, dvt_job *job);
-/* test hook: run K0 on a prepared job and return the device-generated main traces
+size_t dvt_rv32_job_shards(const dvt_job *job);
+int dvt_rv32_commit_shard(dvt_prover *p, const dvt_pk *pk, dvt_job *job, size_t shard, uint32_t header[13]);
+int dvt_rv32_challenges(const uint8_t *vk, size_t vk_len, const uint32_t *headers, size_t n_shards, uint32_t out[8]);
+int dvt_rv32_prove_shard(dvt_prover *p, const dvt_pk *pk, dvt_job *job, size_t shard, const uint32_t challenges[8],
+                         uint8_t **proof, size_t *proof_len);
+int dvt_rv32_assemble(const dvt_job *job, const uint8_t *const *shard_proofs, const size_t *lens, size_t n_shards,
+                      uint8_t **proof, size_t *proof_len);
+/* test hook: run K0 on one shard of a prepared job and return the device-generated main traces
  * (canonical); blob layout as dvt_rv32_debug_traces with prep_width = 0. */
-int dvt_rv32_debug_device_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *job, uint32_t **blob, size_t *blob_words);
+int dvt_rv32_debug_device_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *job, size_t shard, uint32_t **blob,
+                                 size_t *blob_words);
 /* stock `client.verify(&proof,&vk)` semantics (NOT the reference's re-execution
  * `verify` sub-command).  Host-only. */
 int dvt_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, size_t proof_len, uint32_t fri_queries,
                uint32_t pow_bits, int32_t *exit_code, uint8_t **public_values, size_t *pv_len, char **reason);
-/* test hook, host-only: the traces (canonical, column-major) the prover would
- * commit for this run.  Layout of *blob (u32 words): n_chips, then per chip
- * {chip_id, log_n, main_width, prep_width}, then n_pub, pubs..., then per chip the
- * main words followed by the preprocessed words. */
-int dvt_rv32_debug_traces(const uint8_t *elf, size_t elf_len, const dvt_buf *stdin_bufs, size_t nbuf, uint32_t **blob,
-                          size_t *blob_words, char **err_text);
+/* test hook, host-only: the traces (canonical, column-major) the prover would commit for shard
+ * `shard` (0-based position) of this run cut at 2^log_shard cycles (0 = default 21).  Layout of *blob
+ * (u32 words): n_chips present, then per chip {chip_id, log_n, main_width, prep_width}, then n_pub,
+ * pubs..., then per chip the main words followed by the preprocessed words. */
+int dvt_rv32_debug_traces(const uint8_t *elf, size_t elf_len, const dvt_buf *stdin_bufs, size_t nbuf, uint32_t log_shard,
+                          uint32_t shard, uint32_t *n_shards, uint32_t **blob, size_t *blob_words, char **err_text);
 
 #ifdef __cplusplus
 }

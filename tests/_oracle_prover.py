@@ -118,7 +118,35 @@ class Writer:
         return np.array(self.w, dtype=np.uint32).tobytes()
 
 
-def prove_shard(machine, chips, pubs, num_queries, pow_bits):
+def main_root(chips):
+    """phase 1 of a multi-shard proof: Merkle root of the main-trace LDEs of one shard"""
+    orc = _orc.load()
+    ldes = [orc.coset_lde(_a(ch["main"]), 1, G) for ch in chips]
+    return orc.merkle_commit(ldes)[-1].tolist()
+
+
+def global_challenges(prep_root, headers):
+    """LogUp challenges common to all shards (DESIGN.md "Multi-shard"): transcript over the preprocessed
+    root and every shard's header = main root (8) + public values (5)."""
+    ch = Challenger(_orc.load())
+    ch.observe(prep_root)
+    ch.observe([len(headers)])
+    for h in headers:
+        ch.observe(h[:8])
+        ch.observe([len(h) - 8])
+        ch.observe(h[8:])
+    return ch.sample_ext(), ch.sample_ext()
+
+
+def prep_root_of(chips):
+    orc = _orc.load()
+    air_chips = [c for c in chips if c["prep"] is not None and np.asarray(c["prep"]).shape[0] > 0]
+    if not air_chips:
+        return [0] * 8
+    return orc.merkle_commit([orc.coset_lde(_a(c["prep"]), 1, G) for c in air_chips])[-1].tolist()
+
+
+def prove_shard(machine, chips, pubs, num_queries, pow_bits, perm_challenges=None, prep_chips=None):
     """chips: list of dict(chip_id, main [w][N], prep [w][N]) sorted by chip id (every chip of the shard).
     Returns the shard proof bytes and the preprocessed root (8 ints)."""
     orc = _orc.load()
@@ -158,7 +186,12 @@ def prove_shard(machine, chips, pubs, num_queries, pow_bits):
     ch.observe([npub])
     ch.observe(pubs[:npub])
     # 2. permutation
-    perm_alpha, beta = ch.sample_ext(), ch.sample_ext()
+    if perm_challenges is not None:   # common to all shards; bound into this shard's transcript
+        perm_alpha, beta = [int(x) for x in perm_challenges[0]], [int(x) for x in perm_challenges[1]]
+        ch.observe(perm_alpha)
+        ch.observe(beta)
+    else:
+        perm_alpha, beta = ch.sample_ext(), ch.sample_ext()
     perm_cs = [c for c in cs if c["ext_w"]]
     for c in cs:
         c["cumsum"] = [0, 0, 0, 0]

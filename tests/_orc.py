@@ -148,14 +148,17 @@ class AirOracle:
         bad = self.lib.orc_check_constraints(C.byref(self.chips[cid]), _ptr(main), _ptr(prep), log_n, _ptr(pubs), C.byref(bc), C.byref(br))
         return bad, bc.value, br.value
 
-    def logup_unbalanced(self, chips, pubs):
-        """chips: list of dict(chip_id, main, prep).  Returns (count, first offending record)."""
+    def logup_unbalanced(self, chips, pubs=None):
+        """chips: list of dict(chip_id, main, prep) with one `pubs`, or a list of (chips, pubs) groups
+        (one per shard; the multiset is balanced across all of them).  Returns (count, first offending record)."""
+        groups = [(chips, pubs)] if pubs is not None else chips
         ms = self.lib.orc_multiset_new()
-        pubs = self._arr(pubs)
-        for ch in chips:
-            main, prep = self._arr(ch["main"]), self._arr(ch["prep"])
-            log_n = int(ch["main"].shape[1]).bit_length() - 1
-            self.lib.orc_multiset_add_chip(ms, C.byref(self.chips[ch["chip_id"]]), _ptr(main), _ptr(prep), log_n, _ptr(pubs))
+        for gchips, gpubs in groups:
+            gp = self._arr(gpubs)
+            for ch in gchips:
+                main, prep = self._arr(ch["main"]), self._arr(ch["prep"])
+                log_n = int(ch["main"].shape[1]).bit_length() - 1
+                self.lib.orc_multiset_add_chip(ms, C.byref(self.chips[ch["chip_id"]]), _ptr(main), _ptr(prep), log_n, _ptr(gp))
         out = np.zeros(64, np.uint32)
         n = self.lib.orc_multiset_unbalanced(ms, _ptr(out), out.size)
         self.lib.orc_multiset_free(ms)

@@ -11,8 +11,8 @@ from tests import guests
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("which", ["arith", "bignum", "hint"])
-def test_k0_device_traces_equal_host_traces(which):
+@pytest.mark.parametrize("which,log_shard", [("arith", 21), ("bignum", 21), ("hint", 21), ("bignum", 8)])
+def test_k0_device_traces_equal_host_traces(which, log_shard):
     from dvt_circuits_amd import capi
 
     stdin = []
@@ -22,17 +22,20 @@ def test_k0_device_traces_equal_host_traces(which):
         elf = guests.bignum(5, limbs=6)[0]
     else:
         elf, stdin = guests.hint_sum(), [struct.pack("<5I", 9, 8, 7, 6, 5)]
-    host, hpubs = capi.rv32_debug_traces(elf, stdin)
-    p = capi.Prover('{"fri_queries": 8, "pow_bits": 4}')
+    p = capi.Prover('{"fri_queries": 8, "pow_bits": 4, "log_shard_size": %d}' % log_shard)
     pk, _ = p.setup(elf)
     job, _ = p.prepare(pk, stdin)
-    dev, dpubs = p.debug_device_traces(pk, job)
-    assert (dpubs == hpubs).all()
-    for h, d in zip(host, dev):
-        assert h["chip_id"] == d["chip_id"] and h["log_n"] == d["log_n"]
-        diff = np.argwhere(h["main"] != d["main"])
-        detail = [(int(c), int(r), int(h["main"][c, r]), int(d["main"][c, r])) for c, r in diff[:12]]
-        assert diff.size == 0, f"chip {h['chip_id']}: {len(diff)} mismatches, first (col,row,host,dev): {detail}"
+    n = p.job_shards(job)
+    assert n == capi.rv32_debug_traces(elf, stdin, log_shard, 0)[2]
+    for shard in range(n):
+        host, hpubs, _ = capi.rv32_debug_traces(elf, stdin, log_shard, shard)
+        dev, dpubs = p.debug_device_traces(pk, job, shard)
+        assert (dpubs == hpubs).all() and len(host) == len(dev)
+        for h, d in zip(host, dev):
+            assert h["chip_id"] == d["chip_id"] and h["log_n"] == d["log_n"]
+            diff = np.argwhere(h["main"] != d["main"])
+            detail = [(int(c), int(r), int(h["main"][c, r]), int(d["main"][c, r])) for c, r in diff[:12]]
+            assert diff.size == 0, f"shard {shard} chip {h['chip_id']}: {len(diff)} mismatches, first (col,row,host,dev): {detail}"
     p.job_free(job)
     p.pk_free(pk)
     p.close()

@@ -1,7 +1,7 @@
 """THE parity test: the proof bytes produced by the HIP prover must equal, bit for
 bit, the bytes of the oracle's CPU prover (tests/_oracle_prover.py: oracle stage
 restatements in C + a Python duplex challenger) on the same traces and parameters.
-Covers K1-K9 end to end (and K0 through the rv32 case)."""
+Covers K1-K9 end to end (and K0 + multi-shard chaining through the rv32 cases)."""
 import numpy as np
 import pytest
 
@@ -9,7 +9,6 @@ from tests import _oracle_prover, guests, toy_traces
 
 pytestmark = pytest.mark.gpu
 Q, POW = 6, 5
-CFG = '{"fri_queries": %d, "pow_bits": %d}' % (Q, POW)
 
 
 def first_diff(a: bytes, b: bytes):
@@ -19,12 +18,42 @@ def first_diff(a: bytes, b: bytes):
     return (int(d[0]) if len(d) else n), len(wa), len(wb)
 
 
+def split_container(proof: bytes):
+    """-> (exit_code, public value bytes, [shard proof bytes])"""
+    w = np.frombuffer(proof, np.uint32)
+    assert w[0] == 0x32435644
+    n, ec, pvl = int(w[1]), int(w[2]), int(w[3])
+    at = 4 + (pvl + 3) // 4
+    pv = w[4:at].tobytes()[:pvl]
+    shards = []
+    for _ in range(n):
+        ln = int(w[at])
+        shards.append(w[at + 1:at + 1 + ln].tobytes())
+        at += 1 + ln
+    assert at == len(w)
+    return ec, pv, shards
+
+
+def oracle_prove_execution(elf, stdin, log_shard):
+    from dvt_circuits_amd import capi
+
+    shards, i, n = [], 0, 1
+    while i < n:
+        chips, pubs, n = capi.rv32_debug_traces(elf, stdin, log_shard, i)   # host traces == device traces (test_gpu_k0_parity)
+        shards.append((chips, pubs))
+        i += 1
+    prep_root = _oracle_prover.prep_root_of(shards[0][0])
+    headers = [_oracle_prover.main_root(chips) + [int(x) for x in pubs] for chips, pubs in shards]
+    gc = _oracle_prover.global_challenges(prep_root, headers)
+    return [_oracle_prover.prove_shard("rv32", chips, pubs, Q, POW, perm_challenges=gc)[0] for chips, pubs in shards]
+
+
 @pytest.mark.parametrize("shape", [(6, 4, 11), (3, 0, 1), (9, 11, 1500)])
 def test_toy_proof_bytes_equal_oracle(shape):
     from dvt_circuits_amd import capi
 
     prep, main, pubs = toy_traces.build(*shape)
-    p = capi.Prover(CFG)
+    p = capi.Prover('{"fri_queries": %d, "pow_bits": %d}' % (Q, POW))
     pk, vk = p.machine_setup("toy", prep)
     gpu_proof = p.machine_prove(pk, main, pubs)
     chips = [dict(chip_id=cid, main=m, prep=(prep[0][1] if cid == toy_traces.RANGE8 else np.zeros((0, m.shape[1]), np.uint32))) for cid, m in main]
@@ -35,18 +64,20 @@ def test_toy_proof_bytes_equal_oracle(shape):
     p.close()
 
 
-def test_rv32_proof_bytes_equal_oracle():
+@pytest.mark.parametrize("log_shard", [21, 8])
+def test_rv32_proof_bytes_equal_oracle(log_shard):
     from dvt_circuits_amd import capi
 
     elf, want = guests.bignum(2, limbs=3)
-    p = capi.Prover(CFG)
+    p = capi.Prover('{"fri_queries": %d, "pow_bits": %d, "log_shard_size": %d}' % (Q, POW, log_shard))
     pk, vk = p.setup(elf)
     proof, rep = p.prove_core(pk)
-    words = np.frombuffer(proof, np.uint32)
-    body = 4 + (len(want) + 3) // 4
-    shard_gpu = words[body + 1:].tobytes()
-    chips, pubs = capi.rv32_debug_traces(elf)   # host traces == device traces (test_gpu_k0_parity)
-    shard_cpu, _ = _oracle_prover.prove_shard("rv32", chips, pubs, Q, POW)
-    assert shard_gpu == shard_cpu, f"first differing word / lengths: {first_diff(shard_gpu, shard_cpu)}"
+    ec, pv, gpu_shards = split_container(proof)
+    assert ec == 0 and pv == want
+    cpu_shards = oracle_prove_execution(elf, (), log_shard)
+    assert len(gpu_shards) == len(cpu_shards) and (len(gpu_shards) > 1) == (log_shard < 9)
+    for i, (g, c) in enumerate(zip(gpu_shards, cpu_shards)):
+        assert g == c, f"shard {i}: first differing word / lengths: {first_diff(g, c)}"
+    assert capi.verify(vk, proof, Q, POW)[0]
     p.pk_free(pk)
     p.close()

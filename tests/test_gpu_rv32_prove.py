@@ -1,5 +1,6 @@
 """GPU tests of the reference boundary on the rv32 machine: setup(elf) ->
-prove_core(stdin) -> verify, through the C-ABI (reference src/main.rs:461-474)."""
+prove_core(stdin) -> verify, through the C-ABI (reference src/main.rs:461-474),
+single- and multi-shard."""
 import struct
 
 import numpy as np
@@ -9,7 +10,10 @@ from tests import guests
 
 pytestmark = pytest.mark.gpu
 Q, POW = 24, 8
-CFG = '{"fri_queries": %d, "pow_bits": %d}' % (Q, POW)
+
+
+def cfg(log_shard=21):
+    return '{"fri_queries": %d, "pow_bits": %d, "log_shard_size": %d}' % (Q, POW, log_shard)
 
 
 @pytest.fixture(scope="module")
@@ -18,7 +22,7 @@ def gpu():
     from dvt_circuits_amd import capi
 
     assert torch.cuda.is_available()
-    p = capi.Prover(CFG)
+    p = capi.Prover(cfg())
     yield p
     p.close()
 
@@ -40,7 +44,7 @@ def test_arith_guest_proof_verifies(gpu):
     words = np.frombuffer(proof, dtype=np.uint32).copy()
     rng = np.random.default_rng(3)
     body = 4 + (len(want) + 3) // 4
-    for pos in [2, 3, body, body + 1] + list(rng.integers(body + 1, len(words), 20)):
+    for pos in [1, 2, 3, body, body + 1] + list(rng.integers(body + 1, len(words), 20)):
         w = words.copy()
         w[pos] = (int(w[pos]) + 1) % 2013265921
         assert not capi.verify(vk, w.tobytes(), Q, POW)[0], f"tampered word {pos} accepted"
@@ -69,6 +73,42 @@ def test_bignum_and_hint_guests(gpu):
     ok, ec, pv, why = capi.verify(vk, proof, Q, POW)
     assert ok and struct.unpack("<I", pv)[0] == 136, why
     gpu.pk_free(pk)
+
+
+def test_multi_shard_proof(gpu):
+    """one execution cut into 2^10-cycle shards: the shards verify only together (common LogUp
+    challenges, memory bus balanced across shards, pc / shard-index chaining)"""
+    from dvt_circuits_amd import capi
+
+    elf, want = guests.bignum(3, limbs=12)          # ~7k cycles -> 7 shards
+    p = capi.Prover(cfg(10))
+    pk, vk = p.setup(elf)
+    proof, rep = p.prove_core(pk)
+    ok, ec, pv, why = capi.verify(vk, proof, Q, POW)
+    assert ok and pv == want, why
+    w = np.frombuffer(proof, np.uint32)
+    n = int(w[1])
+    assert n == (rep["cycles"] + 1023) // 1024 and n > 4
+    # the shard-level API (what the multi-GPU bench uses) assembles the same bytes
+    job, _ = p.prepare(pk)
+    headers = [p.commit_shard(pk, job, i) for i in range(n)]
+    ch = capi.rv32_challenges(vk, headers)
+    shard_proofs = [p.prove_shard(pk, job, i, ch) for i in range(n)]
+    assert p.assemble(job, shard_proofs) == proof
+    # dropping, swapping or replaying a shard must be rejected
+    assert not capi.verify(vk, p.assemble(job, shard_proofs[:1] + shard_proofs[2:] + shard_proofs[1:2]), Q, POW)[0]
+    at = 4 + (len(want) + 3) // 4
+    first_len = int(w[at])
+    truncated = w.copy()
+    truncated[1] = n - 1
+    cut = np.concatenate([truncated[:at], truncated[at + 1 + first_len:]])
+    assert not capi.verify(vk, cut.tobytes(), Q, POW)[0]
+    # a shard proven under different challenges does not fit
+    bad = p.prove_shard(pk, job, 1, (ch + 1) % 2013265921)
+    assert not capi.verify(vk, p.assemble(job, [shard_proofs[0], bad] + shard_proofs[2:]), Q, POW)[0]
+    p.job_free(job)
+    p.pk_free(pk)
+    p.close()
 
 
 def test_error_classes(gpu):

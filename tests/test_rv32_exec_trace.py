@@ -15,15 +15,24 @@ def air():
     return _orc.air("rv32")
 
 
-def check_traces(air, elf, stdin=()):
-    chips, pubs = capi.rv32_debug_traces(elf, stdin)
-    for ch in chips:
-        bad, bc, br = air.check_constraints(ch["chip_id"], ch["main"], ch["prep"], pubs)
-        name = air.chip(ch["chip_id"]).name.decode()
-        assert bad == 0, f"chip {name}: {bad} violations, first: constraint {bc} at row {br}"
-    n, first = air.logup_unbalanced(chips, pubs)
+def check_traces(air, elf, stdin=(), log_shard=0):
+    """every shard satisfies every constraint; the LogUp multiset balances across ALL shards"""
+    groups, shard, n_shards = [], 0, 1
+    while shard < n_shards:
+        chips, pubs, n_shards = capi.rv32_debug_traces(elf, stdin, log_shard, shard)
+        for ch in chips:
+            bad, bc, br = air.check_constraints(ch["chip_id"], ch["main"], ch["prep"], pubs)
+            name = air.chip(ch["chip_id"]).name.decode()
+            assert bad == 0, f"shard {shard} chip {name}: {bad} violations, first: constraint {bc} at row {br}"
+        assert pubs[3] == shard + 1 and pubs[4] == (1 if shard + 1 == n_shards else 0)
+        assert (len(chips) == 5) == (shard + 1 == n_shards)
+        groups.append((chips, pubs))
+        shard += 1
+    n, first = air.logup_unbalanced(groups)
     assert n == 0, f"{n} unbalanced LogUp tuples, first (bus, arity, mult, values...) = {first}"
-    return chips, pubs
+    for a, b in zip(groups, groups[1:]):
+        assert a[1][1] == b[1][0], "shards do not chain"
+    return groups[-1]
 
 
 def test_arith_guest_executes_and_traces_satisfy_air(air):
@@ -42,6 +51,15 @@ def test_bignum_guest(air):
     assert rc == 0, err
     assert pv == want
     check_traces(air, elf)
+
+
+@pytest.mark.parametrize("log_shard", [5, 7, 8])
+def test_multi_shard_traces(air, log_shard):
+    """the same run cut into many small shards: per-shard constraints + cross-shard memory consistency"""
+    elf, _ = guests.bignum(3, limbs=4)
+    check_traces(air, elf, log_shard=log_shard)
+    elf2 = guests.hint_sum()
+    check_traces(air, elf2, [struct.pack("<8I", *range(8))], log_shard=4)
 
 
 def test_hint_guest(air):
@@ -73,7 +91,7 @@ def test_exit_codes_and_traps():
 def test_tampered_trace_is_caught_by_oracle(air):
     """the checker itself must notice a wrong row (guards against a vacuous oracle)"""
     elf, _ = guests.arith()
-    chips, pubs = capi.rv32_debug_traces(elf)
+    chips, pubs, _ = capi.rv32_debug_traces(elf)
     cpu = next(c for c in chips if air.chip(c["chip_id"]).name == b"cpu")
     m = cpu["main"].copy()
     m[0, 3] = 0  # is_real := 0 in the middle of the real rows

@@ -17,8 +17,12 @@ address and produces a new one with a strictly larger timestamp.
 Words are 4 byte limbs; all limbs written to a register or to memory are
 range-checked through the byte table.  Addresses are < 2^30.
 
-Timestamps inside a shard: instruction i (0-based) has clk = 4(i+1); it reads
-rs2 at clk, rs1 at clk+1, touches memory at clk+2 and writes rd at clk+3.
+Timestamps are pairs (shard, clk), shards numbered from 1; inside a shard instruction
+i (0-based) has clk = 4(i+1); it reads rs2 at clk, rs1 at clk+1, touches memory at
+clk+2 and writes rd at clk+3.  A long execution is cut into shards that are proven
+independently with COMMON LogUp challenges (derived from all shards' main
+commitments), so the memory bus balances across shards; the mem_init table (initial
+tuples at (0,0), final tuples) is part of the last shard only.
 
 DSL conventions: `sel * (...)` gates a family's constraints by its (program-table
 supplied, hence trusted and mutually exclusive) selector.
@@ -39,9 +43,9 @@ FLAGS = [
 # instruction tuple on the program bus: pc, rd, rs1, rs2, imm[4], off[4], tgt, flags...
 N_INSTR_FIELDS = 1 + 3 + 4 + 4 + 1 + len(FLAGS)
 
-PUB_START_PC, PUB_NEXT_PC, PUB_EXIT_CODE = 0, 1, 2
-N_PUB = 3
-UNION_W = 20
+PUB_START_PC, PUB_NEXT_PC, PUB_EXIT_CODE, PUB_SHARD, PUB_IS_LAST = 0, 1, 2, 3, 4
+N_PUB = 5
+UNION_W = 21
 
 
 def build_program():
@@ -79,6 +83,10 @@ def build_cpu():
     # register ports: previous timestamp + 24-bit difference (16 + 8 bit limbs)
     pb_ts, pb_lo, pb_hi = ch.col("pb_ts"), ch.col("pb_lo"), ch.col("pb_hi")
     pc_ts, pc_lo, pc_hi = ch.col("pc_ts"), ch.col("pc_lo"), ch.col("pc_hi")
+    # shard of the previous access of each port and "same shard" flags (timestamps are (shard, clk) pairs)
+    pb_sh, pb_same, pc_sh, pc_same = ch.col("pb_sh"), ch.col("pb_same"), ch.col("pc_sh"), ch.col("pc_same")
+    pa_sh, pa_same = ch.col("pa_sh"), ch.col("pa_same")
+    shard = ch.pub(PUB_SHARD)
     pa_prev = ch.cols("pa_prev", 4)
     pa_ts, pa_lo, pa_hi = ch.col("pa_ts"), ch.col("pa_lo"), ch.col("pa_hi")
     U = ch.cols("u", UNION_W)
@@ -100,15 +108,19 @@ def build_cpu():
     ch.send("program", [pc, rd, rs1, rs2] + imm + off + [tgt] + [F[f] for f in FLAGS], is_real)
 
     # ---------------- register ports (memory bus, addresses 0..31)
-    def port(addr, prev_val, val, prev_ts, ts, lo, hi, en):
-        ch.receive("mem", [addr] + prev_val + [prev_ts], en)
-        ch.send("mem", [addr] + val + [ts], en)
-        ch.assert_zero(en * (ts - prev_ts - 1 - lo - 65536 * hi))
+    def port(addr, prev_val, val, prev_sh, same, prev_ts, ts, lo, hi, en):
+        # consume (addr, value, shard', clk'), produce (addr, value, shard, clk) with (shard', clk') < (shard, clk):
+        # same shard -> clk - clk' - 1 is a 24-bit number; earlier shard -> shard - shard' - 1 is
+        ch.receive("mem", [addr] + prev_val + [prev_sh, prev_ts], en)
+        ch.send("mem", [addr] + val + [shard, ts], en)
+        ch.assert_zero(en * (same * (same - 1)))
+        ch.assert_zero(en * (same * (shard - prev_sh)))
+        ch.assert_zero(en * (same * (ts - prev_ts - 1) + (1 - same) * (shard - prev_sh - 1) - lo - 65536 * hi))
         ch.send("byte", [B_U16, 0, lo, 0], en)
 
-    port(rs2, c, c, pc_ts, clk, pc_lo, pc_hi, F["rs2_en"])
-    port(rs1, b, b, pb_ts, clk + 1, pb_lo, pb_hi, F["rs1_en"])
-    port(rd, pa_prev, a, pa_ts, clk + 3, pa_lo, pa_hi, F["rd_en"])
+    port(rs2, c, c, pc_sh, pc_same, pc_ts, clk, pc_lo, pc_hi, F["rs2_en"])
+    port(rs1, b, b, pb_sh, pb_same, pb_ts, clk + 1, pb_lo, pb_hi, F["rs1_en"])
+    port(rd, pa_prev, a, pa_sh, pa_same, pa_ts, clk + 3, pa_lo, pa_hi, F["rd_en"])
     for i in range(4):
         ch.assert_zero(F["imm_c"] * (c[i] - imm[i]))
 
@@ -198,11 +210,13 @@ def build_cpu():
     ch.assert_zero(F["is_jalr"] * (jl * (jl - 1)))
     ch.assert_zero(F["is_jalr"] * (next_pc - word(s) + jl))
     # LW / SW: u[8..11] memory value after, u[12..15] before, u[16] prev ts, u[17] lo, u[18] hi
-    mv, mp, m_ts, m_lo, m_hi = U[8:12], U[12:16], U[16], U[17], U[18]
+    mv, mp, m_ts, m_lo, m_hi, m_sh, m_same = U[8:12], U[12:16], U[16], U[17], U[18], U[19], U[20]
     ch.send("byte", [B_AND, 0, s[0], 3], sel_mem)             # word aligned
-    ch.receive("mem", [word(s)] + mp + [m_ts], sel_mem)
-    ch.send("mem", [word(s)] + mv + [clk + 2], sel_mem)
-    ch.assert_zero(sel_mem * (clk + 2 - m_ts - 1 - m_lo - 65536 * m_hi))
+    ch.receive("mem", [word(s)] + mp + [m_sh, m_ts], sel_mem)
+    ch.send("mem", [word(s)] + mv + [shard, clk + 2], sel_mem)
+    ch.assert_zero(sel_mem * (m_same * (m_same - 1)))
+    ch.assert_zero(sel_mem * (m_same * (shard - m_sh)))
+    ch.assert_zero(sel_mem * (m_same * (clk + 2 - m_ts - 1) + (1 - m_same) * (shard - m_sh - 1) - m_lo - 65536 * m_hi))
     ch.send("byte", [B_U16, 0, m_lo, 0], sel_mem)
     for i in range(4):
         ch.assert_zero(F["is_lw"] * (a[i] - mv[i]))
@@ -237,13 +251,14 @@ def build_mem_image():
     addr, v, real = ch.prep("addr"), ch.preps("v", 4), ch.prep("is_real")
     pad = ch.col("pad")
     ch.assert_zero(pad)
-    ch.receive("image", [addr] + v, real)
+    # the image is consumed once per execution: by the mem_init table, which only the last shard carries
+    ch.receive("image", [addr] + v, real * ch.pub(PUB_IS_LAST))
     return ch
 
 
 def build_mem_init():
     ch = Chip("mem_init")
-    addr, v, f, fts = ch.col("addr"), ch.cols("v", 4), ch.cols("f", 4), ch.col("fts")
+    addr, v, f, fts, fsh = ch.col("addr"), ch.cols("v", 4), ch.cols("f", 4), ch.col("fts"), ch.col("fsh")
     d = ch.cols("d", 4)
     is_img, is_real = ch.col("is_img"), ch.col("is_real")
     ch.assert_bool(is_real)
@@ -258,8 +273,8 @@ def build_mem_init():
     ch.send("byte", [B_RANGE, 0, v[0], v[1]], is_real - is_img)
     ch.send("byte", [B_RANGE, 0, v[2], v[3]], is_real - is_img)
     ch.send("image", [addr] + v, is_img)
-    ch.send("mem", [addr] + v + [0], is_real)
-    ch.receive("mem", [addr] + f + [fts], is_real)
+    ch.send("mem", [addr] + v + [0, 0], is_real)                  # initial tuple: shard 0, clk 0
+    ch.receive("mem", [addr] + f + [fsh, fts], is_real)          # final tuple: last (shard, clk) that touched it
     return ch
 
 
