@@ -2,12 +2,15 @@
 """Benchmark of the hot path named by BASELINE.json: prover guest-cycles/second
 (and proofs/hour) on MI355X.
 
-A "step" = one pass of the GPU prover (K0 trace expansion .. K9 FRI queries) over
-one shard of the synthetic DKG-like guest (tests/guests.py:bignum, ~2^21 RV32IM
-cycles), with the shard's compact execution records already resident in HBM.
-N > 1: every rank proves its own replica of the shard on its own GPU ("replicas
-only" until multi-shard proofs land, DESIGN.md "Multi-GPU"); no data-path
-collective; value = cycles proven by all ranks / max-over-ranks time.
+A "step" = one proof of one execution of the synthetic DKG-like guest
+(tests/guests.py:bignum): K0 trace expansion .. K9 FRI queries over all its shards
+of 2^21 RV32IM cycles, with the compact execution records already resident in HBM.
+The execution has shards_per_gpu x N shards (weak scaling: N = 1 is the single-shard
+configuration BASELINE.json quotes); shard i is proven on GPU i mod N.  The only
+exchange is an all-gather of the 52-byte shard headers (main-trace root + public
+values) between phase 1 (main commitments) and phase 2 (everything else), from
+which every rank derives the common LogUp challenges.
+value = guest cycles of the execution x steps / max-over-ranks time.
 
 Extra objects on the JSON line (rank 0 prints exactly one line):
   roofline      the dominant HBM-bound kernel family, K1 coset LDE: algorithmic bytes
@@ -66,7 +69,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--iters", type=int, default=900, help="bignum guest iterations (900 -> ~2.08M cycles, one 2^21-row shard)")
+    ap.add_argument("--iters", type=int, default=0, help="bignum guest iterations (default 907 per shard: ~2.096M cycles fill one 2^21-cycle shard)")
+    ap.add_argument("--shards-per-gpu", type=int, default=1, help="weak scaling: the execution has shards_per_gpu x n_gpus shards")
     ap.add_argument("--cpu-small", type=int, default=112)
     ap.add_argument("--cpu-big", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -90,40 +94,83 @@ def main():
         ranks.barrier()
         torch.cuda.synchronize()
 
-    elf, want_pv = guests.bignum(args.iters)
-    prover = capi.Prover('{"device": %d, "fri_queries": 100, "pow_bits": 16}' % local)
+    # workload: one execution of (shards_per_gpu x world) shards of 2^21 cycles; rank r owns shards r, r+world, ...
+    total_shards = args.shards_per_gpu * world
+    iters = args.iters if args.iters else 907 * total_shards
+    elf, want_pv = guests.bignum(iters)
+    prover = capi.Prover('{"device": %d, "fri_queries": 100, "pow_bits": 16, "log_shard_size": 21}' % local)
     pk, vk = prover.setup(elf)
     t_host = time.perf_counter()
     job, rep = prover.prepare(pk)
     t_host = time.perf_counter() - t_host
     cycles = int(rep["cycles"])
+    n_shards = prover.job_shards(job)
+    mine = ranks.shard_of(n_shards)
+
+    def exchange_headers(local_headers):
+        """the one exchange step of the path: all-gather of the 13-word shard headers (RCCL over xGMI)"""
+        import numpy as np
+
+        if world == 1:
+            return np.stack(local_headers)
+        h = torch.zeros((n_shards, 13), dtype=torch.int64, device="cuda")
+        for i, hd in zip(mine, local_headers):
+            h[i] = torch.from_numpy(hd.astype(np.int64)).cuda()
+        ranks.dist.all_reduce(h)   # disjoint rows: sum == gather
+        return h.cpu().numpy().astype(np.uint32)
+
+    def prove_once(want_bytes):
+        headers = exchange_headers([prover.commit_shard(pk, job, i) for i in mine])
+        ch = capi.rv32_challenges(vk, headers)
+        return [prover.prove_shard(pk, job, i, ch, want_bytes=want_bytes) for i in mine]
 
     # correctness outside the timed region: the proof this configuration produces must verify
-    proof = prover.prove_job(pk, job)
-    ok, ec, pv, why = capi.verify(vk, proof, 100, 16)
-    assert ok and pv == want_pv and ec == 0, f"bench proof rejected: {why}"
+    shard_proofs = prove_once(True)
+    if world == 1:
+        proof = prover.assemble(job, shard_proofs)
+        ok, ec, pv, why = capi.verify(vk, proof, 100, 16)
+        assert ok and pv == want_pv and ec == 0, f"bench proof rejected: {why}"
+    else:
+        import numpy as np
+
+        lens = torch.zeros(n_shards, dtype=torch.int64, device="cuda")
+        for i, sp in zip(mine, shard_proofs):
+            lens[i] = len(sp)
+        ranks.dist.all_reduce(lens)
+        mx = int(lens.max().item())
+        buf = torch.zeros((n_shards, mx), dtype=torch.uint8, device="cuda")
+        for i, sp in zip(mine, shard_proofs):
+            buf[i, : len(sp)] = torch.frombuffer(bytearray(sp), dtype=torch.uint8).cuda()
+        ranks.dist.all_reduce(buf)
+        if rank == 0:
+            allp = [bytes(buf[i, : int(lens[i].item())].cpu().numpy()) for i in range(n_shards)]
+            ok, ec, pv, why = capi.verify(vk, prover.assemble(job, allp), 100, 16)
+            assert ok and pv == want_pv and ec == 0, f"bench proof rejected: {why}"
 
     for _ in range(args.warmup):
-        prover.prove_job(pk, job, want_bytes=False)
+        prove_once(False)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        prover.prove_job(pk, job, want_bytes=False)
+        prove_once(False)
     prover.sync()
     barrier()
     dt = ranks.max_over_ranks(time.perf_counter() - t0)
 
     # end-to-end rate including host execution + PCIe upload (reported, never `value`)
-    t1 = time.perf_counter()
-    j2, _ = prover.prepare(pk)
-    prover.prove_job(pk, j2, want_bytes=False)
-    prover.sync()
-    e2e = time.perf_counter() - t1
-    prover.job_free(j2)
+    e2e = None
+    if world == 1:
+        t1 = time.perf_counter()
+        j2, _ = prover.prepare(pk)
+        prover.prove_job(pk, j2, want_bytes=False)
+        prover.sync()
+        e2e = time.perf_counter() - t1
+        prover.job_free(j2)
 
     # kernel-family timing on a profiled handle (HIP events on the prover stream, same shard)
     prof = capi.Prover('{"device": %d, "fri_queries": 100, "pow_bits": 16, "profile": 1}' % local)
-    ppk, _ = prof.setup(elf)
+    pelf, _ = guests.bignum(907)           # one shard
+    ppk, _ = prof.setup(pelf)
     pjob, _ = prof.prepare(ppk)
     prof.prove_job(ppk, pjob, want_bytes=False)
     prof.prove_job(ppk, pjob, want_bytes=False)
@@ -136,7 +183,7 @@ def main():
 
     out = {
         "metric": "SP1 prover cycles/sec + proofs/hour, finalization_prove at 1/2/4/8 MI355X",
-        "value": whole_job_rate(cycles, world, args.steps, dt),
+        "value": cycles * args.steps / dt,
         "unit": "guest cycles/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -151,12 +198,14 @@ def main():
             "workload": "finalization-like synthetic DKG guest (tests/guests.py:bignum, 384-bit multiply-accumulate), one shard of "
                         "~2^21 RV32IM cycles, BASELINE configs[1]; the reference's own guest ELF is prebuilt machine code and is not run",
             "guest_cycles_per_proof": cycles,
+            "shards_per_proof": n_shards,
+            "shards_per_gpu": args.shards_per_gpu,
             "fri_queries": 100,
             "pow_bits": 16,
             "log_blowup": 1,
-            "parallelism": "replicas x%d" % world,
-            "proofs_per_hour": world * args.steps * 3600.0 / dt,
-            "end_to_end_cycles_per_s_incl_host_exec_and_pcie": cycles / e2e,
+            "parallelism": "one execution, shard i on GPU i mod %d; all-gather of 52-byte shard headers between the two phases" % world,
+            "proofs_per_hour": args.steps * 3600.0 / dt,
+            "end_to_end_cycles_per_s_incl_host_exec_and_pcie": (cycles / e2e) if e2e else None,
             "host_prepare_seconds": t_host,
         },
         "roofline": {

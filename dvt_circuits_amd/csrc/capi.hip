@@ -420,6 +420,7 @@ struct ShardJob {
     bool present[5] = {false, false, false, false, false};
     uint32_t *d_aux[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // main traces except cpu
     std::vector<Fp> pubs;
+    MainCache cache;  // phase-1 LDEs + tree of the main traces, consumed by phase 2
 };
 // one prepared execution: executor output cut into shards, resident in HBM, ready for K0..K9
 struct dvt_job {
@@ -434,6 +435,7 @@ static void job_release(dvt_job *j) {
     for (auto &s : j->shards) {
         if (s.d_recs) (void)hipFree(s.d_recs);
         for (auto &d : s.d_aux) if (d) (void)hipFree(d);
+        s.cache.release();
     }
     if (j->d_cpu) (void)hipFree(j->d_cpu);
     if (j->d_byte) (void)hipFree(j->d_byte);
@@ -513,7 +515,11 @@ static int shard_commit(dvt_prover *p, const dvt_pk *pk, dvt_job *j, size_t i, u
     int rc = shard_traces(p, pk, j, i, &traces);
     if (rc) return rc;
     Digest root;
-    if (!p->eng.commit_main_root(pk->key, traces, &root)) return fail(p, DVT_ERR_DEVICE, "%s", p->eng.err.c_str());
+    // keep the phase-1 results in HBM while they fit (about 2 GB per 2^21-cycle shard); otherwise phase 2 recomputes
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    MainCache *keep = (j->shards[i].cache.tree || free_b > ((size_t)24 << 30)) ? &j->shards[i].cache : nullptr;
+    if (!p->eng.commit_main_root(pk->key, traces, &root, keep)) return fail(p, DVT_ERR_DEVICE, "%s", p->eng.err.c_str());
     for (int k = 0; k < 8; k++) header[k] = root.d[k].canonical();
     for (uint32_t k = 0; k < N_PUB; k++) header[8 + k] = j->shards[i].pubs[k].canonical();
     return DVT_OK;
@@ -524,7 +530,10 @@ static int shard_prove(dvt_prover *p, const dvt_pk *pk, dvt_job *j, size_t i, co
     int rc = shard_traces(p, pk, j, i, &traces);
     if (rc) return rc;
     ShardProof sp;
-    if (!p->eng.prove_shard(pk->key, traces, j->shards[i].pubs, p->cfg, &sp, &gc)) return fail(p, DVT_ERR_DEVICE, "%s", p->eng.err.c_str());
+    bool ok = p->eng.prove_shard(pk->key, traces, j->shards[i].pubs, p->cfg, &sp, &gc, &j->shards[i].cache);
+    (void)hipStreamSynchronize(p->eng.stream);
+    j->shards[i].cache.valid = false;  // the buffers stay for the next commit of this shard (released with the job)
+    if (!ok) return fail(p, DVT_ERR_DEVICE, "%s", p->eng.err.c_str());
     WordWriter w;
     write_shard_proof(w, sp);
     *words = std::move(w.w);

@@ -81,6 +81,27 @@ struct ProvingKey {
     uint32_t prep_log_h = 0;  // log2 of the tallest preprocessed LDE
 };
 
+// Phase-1 results of one shard kept in HBM for phase 2 (main-trace LDEs + their Merkle tree), so that the
+// common-challenge protocol does not pay K1-K3 of the main trace twice.  Owned by the caller.
+struct MainCache {
+    bool valid = false;
+    std::vector<uint32_t *> lde;  // one per chip trace, in trace order
+    std::vector<size_t> lde_words;
+    uint32_t *tree = nullptr;
+    uint32_t log_h = 0;
+    Digest root;
+    // buffers are reused by the next commit of a shard of the same shape (benchmarks prove the same job repeatedly)
+    bool fits(const std::vector<size_t> &words, uint32_t h) const { return tree && log_h == h && lde_words == words; }
+    void release() {
+        for (auto p : lde) if (p) (void)hipFree(p);
+        lde.clear();
+        lde_words.clear();
+        if (tree) (void)hipFree(tree);
+        tree = nullptr;
+        valid = false;
+    }
+};
+
 struct StageTimes {  // milliseconds, HIP events on the prover stream (profile mode)
     float commit_main = 0, perm = 0, quotient = 0, open = 0, fri = 0, total = 0;
     // kernel families, summed over the launches of one prove_shard call
@@ -117,9 +138,11 @@ class Engine {
                ProvingKey *pk);
     void free_key(ProvingKey *pk);
     bool prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &traces, const std::vector<Fp> &pubs,
-                     const StarkConfig &cfg, ShardProof *out, const PermChallenges *global = nullptr);
-    // phase 1 of a multi-shard proof: K1-K3 of the main traces only -> main_root (nothing is kept)
-    bool commit_main_root(const ProvingKey &pk, const std::vector<ChipTrace> &traces, Digest *root);
+                     const StarkConfig &cfg, ShardProof *out, const PermChallenges *global = nullptr,
+                     const MainCache *cached = nullptr);
+    // phase 1 of a multi-shard proof: K1-K3 of the main traces only -> main_root; with keep != nullptr the
+    // LDEs and the tree stay in HBM (hipMalloc'ed into *keep) for prove_shard(..., cached = keep)
+    bool commit_main_root(const ProvingKey &pk, const std::vector<ChipTrace> &traces, Digest *root, MainCache *keep = nullptr);
 
     Arena arena;
 

@@ -260,7 +260,9 @@ struct EventTimer {
 };
 }  // namespace
 
-bool Engine::commit_main_root(const ProvingKey &pk, const std::vector<ChipTrace> &traces, Digest *root) {
+bool Engine::commit_main_root(const ProvingKey &pk, const std::vector<ChipTrace> &traces, Digest *root, MainCache *keep) {
+    times = StageTimes();
+    EventTimer t_all(stream, profile);
     HIPCHK(hipSetDevice(device));
     const MachineDesc *m = pk.vk.machine;
     arena.reset();
@@ -278,29 +280,83 @@ bool Engine::commit_main_root(const ProvingKey &pk, const std::vector<ChipTrace>
     uint32_t *d_scratch = arena.alloc<uint32_t>(max_mat_words);
     if (!d_scratch) return fail("commit: device arena exhausted");
     std::vector<DevMat> mats;
+    bool reuse = false;
+    if (keep) {
+        std::vector<size_t> want;
+        for (auto &t : traces) want.push_back(((size_t)m->chips[t.chip_id].main_w << t.log_n) * 2);
+        reuse = keep->fits(want, max_log_n + 1);
+        if (!reuse) { keep->release(); keep->lde_words = want; }
+        keep->valid = false;
+    }
+    size_t ti = 0;
     for (auto &t : traces) {
         const ChipDesc &d = m->chips[t.chip_id];
-        uint32_t *lde = arena.alloc<uint32_t>(((size_t)d.main_w << t.log_n) * 2);
+        uint32_t *lde = nullptr;
+        if (keep && reuse) {
+            lde = keep->lde[ti];
+        } else if (keep) {
+            HIPCHK(hipMalloc(&lde, ((size_t)d.main_w << t.log_n) * 8));
+            keep->lde.push_back(lde);
+        } else {
+            lde = arena.alloc<uint32_t>(((size_t)d.main_w << t.log_n) * 2);
+        }
         if (!lde) return fail("commit: device arena exhausted");
-        HIPCHK(launch_coset_lde(stream, tabs, const_cast<uint32_t *>(t.d_main), d_scratch, lde, d.main_w, t.log_n, 0));
+        {
+            EventTimer t_lde(stream, profile);
+            HIPCHK(launch_coset_lde(stream, tabs, const_cast<uint32_t *>(t.d_main), d_scratch, lde, d.main_w, t.log_n, 0));
+            if (profile) {
+                times.lde_ms += t_lde.stop();
+                times.lde_alg_bytes += 12.0 * d.main_w * (double)((size_t)1 << t.log_n);
+                times.lde_calls++;
+            }
+        }
         mats.push_back({lde, (uint32_t)d.main_w, t.log_n + 1});
+        ti++;
     }
     const uint32_t hmax = max_log_n + 1;
-    uint32_t *tree = arena.alloc<uint32_t>((((size_t)2 << hmax) - 1) * 8);
+    uint32_t *tree = nullptr;
+    if (keep && reuse) {
+        tree = keep->tree;
+    } else if (keep) {
+        HIPCHK(hipMalloc(&tree, (((size_t)2 << hmax) - 1) * 32));
+        keep->tree = tree;
+        keep->log_h = hmax;
+    } else {
+        tree = arena.alloc<uint32_t>((((size_t)2 << hmax) - 1) * 8);
+    }
     if (!tree) return fail("commit: device arena exhausted");
-    if (!commit_tree(mats, tree)) return false;
+    {
+        EventTimer t_mk(stream, profile);
+        if (!commit_tree(mats, tree)) return false;
+        if (profile) {
+            times.merkle_ms += t_mk.stop();
+            for (uint32_t lh = 0; lh <= hmax; lh++) {
+                uint32_t w = 0;
+                for (auto &mm : mats) if (mm.log_h == lh) w += mm.width;
+                double rows = (double)((size_t)1 << lh);
+                times.merkle_perms += lh == hmax ? rows * ((w + 7) / 8) : rows * (1 + (w ? 1 + (w + 7) / 8 : 0));
+            }
+        }
+    }
     uint32_t rootw[8];
     if (!download(rootw, tree + ((((size_t)2 << hmax) - 1) * 8) - 8, 32)) return false;
     for (int i = 0; i < 8; i++) root->d[i] = Fp::raw(rootw[i]);
+    if (keep) { keep->root = *root; keep->valid = true; }
+    if (profile) times.commit_main = t_all.stop();
     return true;
 }
 
 bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &traces, const std::vector<Fp> &pubs,
-                         const StarkConfig &cfg, ShardProof *out, const PermChallenges *global) {
+                         const StarkConfig &cfg, ShardProof *out, const PermChallenges *global, const MainCache *cached) {
     HIPCHK(hipSetDevice(device));
     const MachineDesc *m = pk.vk.machine;
     arena.reset();
+    const StageTimes phase1 = times;
     times = StageTimes();
+    if (cached && cached->valid) {  // carry the phase-1 measurements of this shard into its totals
+        times.lde_ms = phase1.lde_ms; times.lde_alg_bytes = phase1.lde_alg_bytes; times.lde_calls = phase1.lde_calls;
+        times.merkle_ms = phase1.merkle_ms; times.merkle_perms = phase1.merkle_perms;
+    }
     EventTimer tm(stream, profile), tm_total(stream, profile);
     // per-family timing (profile mode only: the extra event synchronisations serialise the stream)
     auto lde = [&](uint32_t *in, uint32_t *scratch, uint32_t *outp, uint32_t width, uint32_t log_n, uint32_t mode) -> hipError_t {
@@ -397,21 +453,28 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
 
     // ---- 1. main trace: LDE + commit  (K1, K2, K3)
     std::vector<DevMat> mats;
-    for (auto &s : cs) {
-        ALLOC(s.main_lde, uint32_t, (size_t)s.d->main_w * 2 * s.n);
-        HIPCHK(lde(const_cast<uint32_t *>(s.main), d_scratch, s.main_lde, s.d->main_w, s.log_n, 0));
-        mats.push_back({s.main_lde, (uint32_t)s.d->main_w, s.log_n + 1});
-    }
     uint32_t *d_main_tree;
-    ALLOC(d_main_tree, uint32_t, tree_words(hmax));
-    if (!commit(mats, d_main_tree)) return false;
     uint32_t rootw[8];
-    if (!download(rootw, tree_root(d_main_tree, hmax), 32)) return false;
-    pf.main_root = digest_from_words(rootw);
+    if (cached && cached->valid) {  // phase 1 already did K1-K3 of the main traces and kept the results
+        if (cached->lde.size() != cs.size() || cached->log_h != hmax) return fail("prove: main-trace cache does not match the shard");
+        for (size_t k = 0; k < cs.size(); k++) cs[k].main_lde = cached->lde[k];
+        d_main_tree = cached->tree;
+        pf.main_root = cached->root;
+    } else {
+        for (auto &s : cs) {
+            ALLOC(s.main_lde, uint32_t, (size_t)s.d->main_w * 2 * s.n);
+            HIPCHK(lde(const_cast<uint32_t *>(s.main), d_scratch, s.main_lde, s.d->main_w, s.log_n, 0));
+            mats.push_back({s.main_lde, (uint32_t)s.d->main_w, s.log_n + 1});
+        }
+        ALLOC(d_main_tree, uint32_t, tree_words(hmax));
+        if (!commit(mats, d_main_tree)) return false;
+        if (!download(rootw, tree_root(d_main_tree, hmax), 32)) return false;
+        pf.main_root = digest_from_words(rootw);
+    }
     ch.observe(pf.main_root);
     ch.observe_u32((uint32_t)pubs.size());
     for (auto x : pubs) ch.observe(x);
-    times.commit_main = tm.stop();
+    times.commit_main = tm.stop() + (cached && cached->valid ? phase1.commit_main : 0.f);
 
     // ---- 2. permutation trace (K4) + LDE + commit
     Fp4 perm_alpha, beta;
@@ -719,7 +782,7 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
         }
     }
     times.fri = tm.stop();
-    times.total = tm_total.stop();
+    times.total = tm_total.stop() + (cached && cached->valid ? phase1.commit_main : 0.f);
     return true;
 #undef ALLOC
 }
