@@ -7,7 +7,7 @@ A "step" = one proof of one execution of the synthetic DKG-like guest
 of 2^21 RV32IM cycles, with the compact execution records already resident in HBM.
 The execution has shards_per_gpu x N shards (weak scaling: N = 1 is the single-shard
 configuration BASELINE.json quotes); shard i is proven on GPU i mod N.  The only
-exchange is an all-gather of the 52-byte shard headers (main-trace root + public
+exchange is an all-gather of the 60-byte shard headers (main-trace root + public
 values) between phase 1 (main commitments) and phase 2 (everything else), from
 which every rank derives the common LogUp challenges.
 value = guest cycles of the execution x steps / max-over-ranks time.
@@ -108,12 +108,12 @@ def main():
     mine = ranks.shard_of(n_shards)
 
     def exchange_headers(local_headers):
-        """the one exchange step of the path: all-gather of the 13-word shard headers (RCCL over xGMI)"""
+        """the one exchange step of the path: all-gather of the 15-word shard headers (RCCL over xGMI)"""
         import numpy as np
 
         if world == 1:
             return np.stack(local_headers)
-        h = torch.zeros((n_shards, 13), dtype=torch.int64, device="cuda")
+        h = torch.zeros((n_shards, 15), dtype=torch.int64, device="cuda")
         for i, hd in zip(mine, local_headers):
             h[i] = torch.from_numpy(hd.astype(np.int64)).cuda()
         ranks.dist.all_reduce(h)   # disjoint rows: sum == gather
@@ -203,7 +203,7 @@ def main():
             "fri_queries": 100,
             "pow_bits": 16,
             "log_blowup": 1,
-            "parallelism": "one execution, shard i on GPU i mod %d; all-gather of 52-byte shard headers between the two phases" % world,
+            "parallelism": "one execution, shard i on GPU i mod %d; all-gather of 60-byte shard headers between the two phases" % world,
             "proofs_per_hour": args.steps * 3600.0 / dt,
             "end_to_end_cycles_per_s_incl_host_exec_and_pcie": (cycles / e2e) if e2e else None,
             "host_prepare_seconds": t_host,

@@ -176,9 +176,9 @@ def rv32_debug_traces(elf: bytes, stdin=(), log_shard=0, shard=0):
 
 
 def rv32_challenges(vk: bytes, headers):
-    """Host-only: the LogUp challenges common to all shards, from their 13-word headers (in shard order)."""
+    """Host-only: the LogUp challenges common to all shards, from their 15-word headers (in shard order)."""
     lib = load()
-    h = np.ascontiguousarray(headers, dtype=np.uint32).reshape(-1, 13)
+    h = np.ascontiguousarray(headers, dtype=np.uint32).reshape(-1, 15)
     out = np.zeros(8, np.uint32)
     rc = lib.dvt_rv32_challenges(vk, len(vk), h.ctypes.data_as(u32p), h.shape[0], out.ctypes.data_as(u32p))
     if rc:
@@ -342,7 +342,7 @@ class Prover:
         return int(self.lib.dvt_rv32_job_shards(job))
 
     def commit_shard(self, pk, job, shard):
-        h = np.zeros(13, np.uint32)
+        h = np.zeros(15, np.uint32)
         self.check(self.lib.dvt_rv32_commit_shard(self.h, pk, job, shard, h.ctypes.data_as(u32p)))
         return h
 

@@ -372,7 +372,7 @@ int dvt_last_stage_ms(dvt_prover *p, float out[6]) {
 // ====================================================================== rv32 boundary
 namespace {
 constexpr uint32_t CORE_PROOF_MAGIC = 0x32435644u;  // "DVC2"
-constexpr uint32_t N_PUB = 5;                        // start_pc, next_pc, exit_code, shard, is_last
+constexpr uint32_t N_PUB = rv32::N_PUBLIC;           // start_pc, next_pc, exit_code, shard, is_last, pv_start, pv_end
 constexpr uint32_t HEADER_WORDS = 8 + N_PUB;         // per-shard commitment header: main root + public values (canonical)
 
 std::vector<std::vector<uint8_t>> collect_stdin(const dvt_buf *bufs, size_t n) {
@@ -415,6 +415,7 @@ PermChallenges global_challenges(const VerifyingKey &vk, const uint32_t *headers
 struct ShardJob {
     uint32_t index = 0;
     size_t n_recs = 0;
+    uint32_t pv_end = 0;
     rv32::CycleRec *d_recs = nullptr;
     uint32_t log_n[5] = {0, 0, 0, 0, 0};
     bool present[5] = {false, false, false, false, false};
@@ -465,6 +466,7 @@ static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_buf
         auto &recs = j->res.shards[si].recs;
         s.index = j->res.shards[si].index;
         s.n_recs = recs.size();
+        s.pv_end = j->res.shards[si].pv_end;
         for (int c = 0; c < m->n_chips; c++) { s.log_n[c] = T.log_n[c]; s.present[c] = T.present[c]; }
         max_log_cpu = std::max(max_log_cpu, s.log_n[RV32_CHIP_CPU]);
         ok = hipMalloc(&s.d_recs, s.n_recs * sizeof(rv32::CycleRec)) == hipSuccess &&
@@ -497,7 +499,7 @@ static int shard_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *j, size_t i, s
     const MachineDesc *m = machine_rv32();
     bool ok = hipMemcpyAsync(j->d_byte, s.d_aux[RV32_CHIP_BYTE], j->byte_words * 4, hipMemcpyDeviceToDevice, st) == hipSuccess &&
               hipMemcpyAsync(j->d_prog, s.d_aux[RV32_CHIP_PROGRAM], j->prog_words * 4, hipMemcpyDeviceToDevice, st) == hipSuccess &&
-              rv32::launch_k0_cpu_rows(st, s.d_recs, s.n_recs, s.index, pk->d_instrs, pk->d_prog_row, j->d_cpu, s.log_n[RV32_CHIP_CPU], j->d_byte,
+              rv32::launch_k0_cpu_rows(st, s.d_recs, s.n_recs, s.index, s.pv_end, pk->d_instrs, pk->d_prog_row, j->d_cpu, s.log_n[RV32_CHIP_CPU], j->d_byte,
                                        j->d_prog) == hipSuccess &&
               launch_to_internal(st, j->d_byte, j->byte_words) == hipSuccess && launch_to_internal(st, j->d_prog, j->prog_words) == hipSuccess;
     if (!ok) return fail(p, DVT_ERR_DEVICE, "trace generation (K0) failed: %s", hipGetErrorString(hipGetLastError()));
@@ -669,7 +671,7 @@ void dvt_job_free(dvt_prover *p, dvt_job *job) {
 }
 size_t dvt_rv32_job_shards(const dvt_job *job) { return job ? job->shards.size() : 0; }
 
-int dvt_rv32_commit_shard(dvt_prover *p, const dvt_pk *pk, dvt_job *job, size_t shard, uint32_t header[13]) {
+int dvt_rv32_commit_shard(dvt_prover *p, const dvt_pk *pk, dvt_job *job, size_t shard, uint32_t header[15]) {
     if (!p || !pk || !job || !header || shard >= job->shards.size()) return fail(p, DVT_ERR_INPUT, "bad argument");
     std::lock_guard<std::mutex> lk(p->mu);
     HIP_TRY(p, hipSetDevice(p->eng.device));
@@ -779,6 +781,9 @@ int dvt_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, size_t pr
             if (last && pubv[1] != 0) return reject(DVT_ERR_REJECTED, "execution did not halt");
             if (!last && pubv[1] == 0) return reject(DVT_ERR_REJECTED, "halt before the last shard");
             if (last && pubv[2] != ec % P) return reject(DVT_ERR_REJECTED, "exit code mismatch");
+            if (pubv[5] != (i ? sps[i - 1].public_values[6].canonical() : 0u)) return reject(DVT_ERR_REJECTED, "public-value counters do not chain");
+            if (pubv[6] < pubv[5]) return reject(DVT_ERR_REJECTED, "public-value counter decreases");
+            if (last && (pvl % 4 || pubv[6] != pvl / 4)) return reject(DVT_ERR_REJECTED, "number of committed public-value words does not match");
             // chip set: every chip in the last shard, all but mem_init in the others
             const size_t want = last ? (size_t)machine_rv32()->n_chips : (size_t)machine_rv32()->n_chips - 1;
             if (sp.chips.size() != want) return reject(DVT_ERR_REJECTED, "unexpected chip set in shard");
@@ -795,7 +800,20 @@ int dvt_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, size_t pr
             if (!why.empty()) return reject(DVT_ERR_REJECTED, "shard " + std::to_string(i + 1) + ": " + why);
             total += t;
         }
-        if (total != Fp4::zero()) return reject(DVT_ERR_REJECTED, "LogUp cumulative sums do not cancel across the shards");
+        // the receiving side of the public-values bus is supplied here, from the claimed bytes:
+        // word k contributes 1 / (alpha + bus + beta*k + beta^2 b0 + ... + beta^5 b3)
+        {
+            Fp4 bp[5];
+            bp[0] = gc.beta;
+            for (int k = 1; k < 5; k++) bp[k] = bp[k - 1] * gc.beta;
+            Fp4 expect = Fp4::zero();
+            for (uint32_t k = 0; k < pvl / 4; k++) {
+                Fp4 d = gc.alpha + Fp::from_canonical(5) + bp[0] * Fp::from_canonical(k);
+                for (int b = 0; b < 4; b++) d += bp[1 + b] * Fp::from_canonical(pv[4 * k + b]);
+                expect += inv(d);
+            }
+            if (total != expect) return reject(DVT_ERR_REJECTED, "LogUp cumulative sums do not cancel across the shards (memory bus or public values)");
+        }
         if (exit_code) *exit_code = (int32_t)ec;
         if (public_values) *public_values = dup_bytes(pv, pv_len);
     } catch (const std::exception &e) { return reject(DVT_ERR_REJECTED, e.what()); }

@@ -8,8 +8,9 @@
 //     registers start at 0; pc starts at e_entry; all addresses < 2^30.
 //   - ecall: t0 = syscall id, a0..a2 = arguments; ids follow the SP1 v3 guest ABI
 //     observed in the reference's bundled guest:
-//     0x00 HALT(a0 = exit code), 0x02 WRITE(fd,ptr,len), 0x10 COMMIT, 0x1A
-//     COMMIT_DEFERRED_PROOFS, 0xF0 HINT_LEN (-> t0), 0xF1 HINT_READ(ptr,len).
+//     0x00 HALT(a0 = exit code), 0x02 WRITE(fd,ptr,len), 0x10 COMMIT(a0 = word: appends a
+//     32-bit word to the public values, which the proof binds), 0x1A COMMIT_DEFERRED_PROOFS
+//     (no-op), 0xF0 HINT_LEN (-> t0), 0xF1 HINT_READ(ptr,len).  WRITE is not part of the statement.
 //     stdin is a list of byte buffers (SP1Stdin::write, src/main.rs:434-437).
 //   - instructions without a chip yet (shifts, mulh/mulhsu, div/rem, sub-word
 //     loads/stores) execute, but a program that retires one cannot be proven:
@@ -33,6 +34,8 @@ enum Flag : uint32_t {
 constexpr uint32_t B_AND = 1, B_OR = 2, B_XOR = 3, B_LTU = 4, B_MSB = 5, B_RANGE = 6, B_U16 = 7;
 constexpr int N_BYTE_OPS = 7;  // multiplicity columns of the byte chip, in this order: and or xor ltu msb range u16
 constexpr uint32_t ADDR_LIMIT = 1u << 30;
+constexpr uint32_t SYS_COMMIT = 0x10;
+constexpr uint32_t N_PUBLIC = 7;  // start_pc, next_pc, exit_code, shard, is_last, pv_start, pv_end
 
 struct Instr {
     uint32_t pc, rd, rs1, rs2, imm, off, tgt, flags;
@@ -55,6 +58,7 @@ struct CycleRec {
     uint32_t next_pc;
     uint32_t m_val, m_prev, m_ts;
     uint32_t pa_sh, pb_sh, pc_sh, m_sh;
+    uint32_t pv_idx;   // public-value words committed (COMMIT ecalls) before this instruction
 };
 
 struct MemInitRow {
@@ -64,6 +68,7 @@ struct MemInitRow {
 // One shard = up to 2^log_shard consecutive cycles; shards are numbered from 1.
 struct ShardRec {
     uint32_t index = 0, start_pc = 0, next_pc = 0;
+    uint32_t pv_start = 0, pv_end = 0;   // committed public-value words before / after this shard
     std::vector<CycleRec> recs;
 };
 
@@ -109,6 +114,7 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
         s.put(RV32_CPU_pa_prev_0 + i, B(r.pa_prev, i));
     }
     s.put(RV32_CPU_tgt, in.tgt);
+    s.put(RV32_CPU_pv_idx, r.pv_idx);
     for (uint32_t k = 0; k < N_FLAGS; k++) s.put(RV32_CPU_rd_en + k, F(k));
     s.prog(r.idx);
     // register ports
@@ -210,6 +216,10 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
         uint32_t idc = b % P;
         s.put(U + 0, idc == 0);
         if (idc) s.put(U + 1, inv(Fp::from_canonical(idc)).canonical());
+        const bool is_commit = idc == SYS_COMMIT;
+        s.put(U + 2, is_commit);
+        if (!is_commit) s.put(U + 3, inv(Fp::from_canonical(idc) - Fp::from_canonical(SYS_COMMIT)).canonical());
+        s.put(RV32_CPU_commit_m, is_commit);
     }
     s.byte(B_RANGE - 1, (pb_hi << 8) | pc_hi);
     s.byte(B_RANGE - 1, (pa_hi << 8) | m_hi);
@@ -225,7 +235,7 @@ struct HostTraces {
     uint32_t log_n[5];
     bool present[5];
     std::vector<uint32_t> main[5];
-    std::vector<uint32_t> pubs;   // start_pc, next_pc, exit_code, shard, is_last
+    std::vector<uint32_t> pubs;   // start_pc, next_pc, exit_code, shard, is_last, pv_start, pv_end
 };
 // preprocessed traces (program, byte, mem_image) for setup
 struct HostPrep {
@@ -242,7 +252,7 @@ bool build_aux_host(const Program &prog, const ExecResult &res, size_t shard_pos
 std::vector<uint32_t> program_row_map(const Program &prog);
 
 #if defined(__HIPCC__)
-hipError_t launch_k0_cpu_rows(hipStream_t st, const CycleRec *d_recs, size_t n_recs, uint32_t shard, const Instr *d_instrs,
+hipError_t launch_k0_cpu_rows(hipStream_t st, const CycleRec *d_recs, size_t n_recs, uint32_t shard, uint32_t pv_end, const Instr *d_instrs,
                               const uint32_t *d_prog_row, uint32_t *d_cpu, uint32_t log_n, uint32_t *d_byte_mult, uint32_t *d_prog_mult);
 #endif
 

@@ -151,17 +151,20 @@ void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin
     const uint64_t shard_cycles = (uint64_t)1 << log_shard;
     uint32_t shard = 1;   // current shard index (timestamps are (shard, clk))
     uint32_t in_shard = 0;  // instructions retired in the current shard
+    uint32_t pv_count = 0;  // public-value words committed so far
     if (trace) { R.shards.emplace_back(); R.shards.back().index = 1; R.shards.back().start_pc = pc; }
     auto trap = [&](const std::string &m) { R.error = m + " at pc 0x" + [&] { char b[16]; snprintf(b, sizeof b, "%x", pc); return std::string(b); }(); };
     while (R.cycles < max_cycles) {
         if (pc < prog.text_base || pc % 4 || (pc - prog.text_base) / 4 >= ninstr) { trap("pc outside text"); return; }
         if (trace && in_shard == shard_cycles) {  // cut a shard
             R.shards.back().next_pc = pc;
+            R.shards.back().pv_end = pv_count;
             shard++;
             in_shard = 0;
             R.shards.emplace_back();
             R.shards.back().index = shard;
             R.shards.back().start_pc = pc;
+            R.shards.back().pv_start = pv_count;
         }
         const uint32_t idx = (pc - prog.text_base) / 4;
         const Instr &in = prog.instrs[idx];
@@ -169,6 +172,7 @@ void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin
         const uint32_t clk = 4 * (in_shard + 1);
         CycleRec rec{};
         rec.idx = idx;
+        rec.pv_idx = pv_count;
         uint32_t next_pc = pc + 4, a = 0, b = 0, c = 0;
         if (!in.supported) {
             // executes but cannot be proven: plain interpreter semantics
@@ -269,11 +273,15 @@ void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin
                     uint32_t ad = a1 + k;
                     if (ad < 32 || ad >= ADDR_LIMIT) { trap("WRITE buffer out of range"); return; }
                     uint8_t by = (uint8_t)(mem.at(ad & ~3u).val >> (8 * (ad & 3)));
-                    if (c == 3) R.public_values.push_back(by); else R.stdout_bytes.push_back(by);
+                    R.stdout_bytes.push_back(by);  // (fd 3 included: only COMMIT words are public values)
                 }
                 break;
             }
-            case 0x10: case 0x1a: break;  // COMMIT / COMMIT_DEFERRED_PROOFS: digest words (binding to public values: next round)
+            case 0x10:  // COMMIT(a0 = word): the next public-value word (bound by the proof)
+                for (int q = 0; q < 4; q++) R.public_values.push_back((uint8_t)(c >> (8 * q)));
+                pv_count++;
+                break;
+            case 0x1a: break;  // COMMIT_DEFERRED_PROOFS: no-op (no recursion in core proofs)
             case 0xf0: a = next_input < stdin_bufs.size() ? (uint32_t)stdin_bufs[next_input].size() : 0; break;
             case 0xf1: {  // HINT_READ(ptr = a0, len = a1): the words become initial memory (must be untouched so far)
                 if (next_input >= stdin_bufs.size()) { trap("HINT_READ with no input left"); return; }
@@ -303,6 +311,7 @@ void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin
     if (!R.halted && R.error.empty()) R.error = "cycle limit reached before HALT";
     if (trace) {
         R.shards.back().next_pc = pc;  // 0 after HALT
+        R.shards.back().pv_end = pv_count;
         // one mem_init row per image word and per touched non-image word, sorted by address
         std::map<uint32_t, MemInitRow> rows;
         for (auto &kv : prog.image) {
@@ -440,7 +449,7 @@ bool build_aux_host(const Program &prog, const ExecResult &res, size_t shard_pos
     T.main[RV32_CHIP_BYTE] = byte_mult;  // [7][65536] already column-major in op order
     T.log_n[RV32_CHIP_MEM_IMAGE] = prep.log_n[RV32_CHIP_MEM_IMAGE];
     T.main[RV32_CHIP_MEM_IMAGE].assign((size_t)1 << T.log_n[RV32_CHIP_MEM_IMAGE], 0);
-    T.pubs = {S.start_pc % P, S.next_pc % P, last ? (uint32_t)res.exit_code % P : 0u, S.index, last ? 1u : 0u};
+    T.pubs = {S.start_pc % P, S.next_pc % P, last ? (uint32_t)res.exit_code % P : 0u, S.index, last ? 1u : 0u, S.pv_start, S.pv_end};
     return true;
 }
 
@@ -456,6 +465,7 @@ bool build_traces_host(const Program &prog, const ExecResult &res, size_t shard_
         sink.row = r;
         fill_cpu_row(S.recs[r], prog.instrs[S.recs[r].idx], (uint32_t)r, S.index, sink);
     }
+    for (size_t r = S.recs.size(); r < nc; r++) T.main[RV32_CHIP_CPU][(size_t)RV32_CPU_pv_idx * nc + r] = S.pv_end;
     // program multiplicities follow the preprocessed row order (provable instructions only)
     std::vector<uint32_t> rowmap = program_row_map(prog);
     for (size_t i = 0; i < prog.instrs.size(); i++)

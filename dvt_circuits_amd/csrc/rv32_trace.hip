@@ -59,7 +59,7 @@ struct DeviceSink {
     __device__ void prog(uint32_t idx) { count(K0_PROG_KEY_BASE + prog_row[idx]); }
 };
 
-__global__ void __launch_bounds__(256) k0_cpu_rows_kernel(const CycleRec *recs, size_t n_recs, uint32_t shard, const Instr *instrs, const uint32_t *prog_row,
+__global__ void __launch_bounds__(256) k0_cpu_rows_kernel(const CycleRec *recs, size_t n_recs, uint32_t shard, uint32_t pv_end, const Instr *instrs, const uint32_t *prog_row,
                                                          uint32_t *cpu, uint32_t log_n, uint32_t *byte_mult, uint32_t *prog_mult) {
     __shared__ uint32_t keys[K0_SLOTS], counts[K0_SLOTS];
     for (uint32_t s = threadIdx.x; s < K0_SLOTS; s += blockDim.x) { keys[s] = K0_EMPTY; counts[s] = 0; }
@@ -73,6 +73,9 @@ __global__ void __launch_bounds__(256) k0_cpu_rows_kernel(const CycleRec *recs, 
             const Instr in = instrs[rec.idx];
             sink.row = r;
             fill_cpu_row(rec, in, (uint32_t)r, shard, sink);
+        } else if (r < sink.n) {
+            sink.row = r;
+            sink.put(RV32_CPU_pv_idx, pv_end);   // padding rows keep the running count of committed words
         }
     }
     __syncthreads();
@@ -80,12 +83,12 @@ __global__ void __launch_bounds__(256) k0_cpu_rows_kernel(const CycleRec *recs, 
         if (keys[s] != K0_EMPTY && counts[s]) sink.global_add(keys[s], counts[s]);
 }
 
-hipError_t launch_k0_cpu_rows(hipStream_t st, const CycleRec *d_recs, size_t n_recs, uint32_t shard, const Instr *d_instrs,
+hipError_t launch_k0_cpu_rows(hipStream_t st, const CycleRec *d_recs, size_t n_recs, uint32_t shard, uint32_t pv_end, const Instr *d_instrs,
                               const uint32_t *d_prog_row, uint32_t *d_cpu, uint32_t log_n, uint32_t *d_byte_mult, uint32_t *d_prog_mult) {
     hipError_t e = hipMemsetAsync(d_cpu, 0, ((size_t)RV32_CPU_MAIN_W << log_n) * 4, st);
     if (e != hipSuccess) return e;
-    unsigned blocks = (unsigned)((n_recs + K0_ROWS_PER_BLOCK - 1) / K0_ROWS_PER_BLOCK);
-    k0_cpu_rows_kernel<<<blocks, 256, 0, st>>>(d_recs, n_recs, shard, d_instrs, d_prog_row, d_cpu, log_n, d_byte_mult, d_prog_mult);
+    unsigned blocks = (unsigned)((((size_t)1 << log_n) + K0_ROWS_PER_BLOCK - 1) / K0_ROWS_PER_BLOCK);
+    k0_cpu_rows_kernel<<<blocks, 256, 0, st>>>(d_recs, n_recs, shard, pv_end, d_instrs, d_prog_row, d_cpu, log_n, d_byte_mult, d_prog_mult);
     return hipGetLastError();
 }
 

@@ -152,8 +152,8 @@ int dvt_prove_core(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_bufs, s
 /* dvt_prove_core in pieces, so that callers (and bench.py) can keep an execution resident in HBM and
  * spread its shards over several GPUs.  An execution is cut into shards of 2^log_shard_size cycles
  * (cfg "log_shard_size", default 21).  All shards are proven with COMMON LogUp challenges derived
- * from every shard's 13-word header (main-trace Merkle root + 5 public values), which is the one
- * exchange step of the path (an all-gather of 52 bytes per shard):
+ * from every shard's 15-word header (main-trace Merkle root + 7 public values), which is the one
+ * exchange step of the path (an all-gather of 60 bytes per shard):
  *   prepare        host execution + upload of the compact per-cycle records and auxiliary traces
  *   commit_shard   phase 1 of shard i: K0 + K1..K3 of the main traces -> header
  *   challenges     host-only: the common challenges from ALL headers (in shard order)
@@ -166,7 +166,7 @@ int dvt_rv32_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_bufs,
 int dvt_rv32_prove_job(dvt_prover *p, const dvt_pk *pk, dvt_job *job, uint8_t **proof, size_t *proof_len);
 void dvt_job_free(dvt_prover *p, dvt_job *job);
 size_t dvt_rv32_job_shards(const dvt_job *job);
-int dvt_rv32_commit_shard(dvt_prover *p, const dvt_pk *pk, dvt_job *job, size_t shard, uint32_t header[13]);
+int dvt_rv32_commit_shard(dvt_prover *p, const dvt_pk *pk, dvt_job *job, size_t shard, uint32_t header[15]);
 int dvt_rv32_challenges(const uint8_t *vk, size_t vk_len, const uint32_t *headers, size_t n_shards, uint32_t out[8]);
 int dvt_rv32_prove_shard(dvt_prover *p, const dvt_pk *pk, dvt_job *job, size_t shard, const uint32_t challenges[8],
                          uint8_t **proof, size_t *proof_len);

@@ -108,6 +108,10 @@ void orc_multiset_add_chip(orc_multiset *ms, const orc_chip_air *chip, const uin
     free(ml); free(mn); free(pl); free(pn); free(mult); free(vals);
 }
 
+void orc_multiset_add_tuple(orc_multiset *ms, uint32_t bus, const uint32_t *vals, uint32_t arity, int sign, uint32_t mult) {
+    ms_insert(ms, bus, vals, arity, sign > 0 ? mult : bb_neg(mult));
+}
+
 size_t orc_multiset_unbalanced(const orc_multiset *ms, uint32_t *out, size_t out_cap) {
     size_t bad = 0;
     for (size_t i = 0; i < ms->cap; i++) {

@@ -50,6 +50,8 @@ orc_multiset *orc_multiset_new(void);
 void orc_multiset_free(orc_multiset *ms);
 void orc_multiset_add_chip(orc_multiset *ms, const orc_chip_air *chip, const uint32_t *main, const uint32_t *prep,
                            uint32_t log_n, const uint32_t *pub);
+/* one explicit tuple (e.g. the verifier-side receives of the public-values bus) */
+void orc_multiset_add_tuple(orc_multiset *ms, uint32_t bus, const uint32_t *vals, uint32_t arity, int sign, uint32_t mult);
 /* number of tuples whose signed multiplicities do not cancel (mod p); the first
  * one is copied to out[0] = bus, out[1] = arity, out[2] = net multiplicity, out[3..] = values */
 size_t orc_multiset_unbalanced(const orc_multiset *ms, uint32_t *out, size_t out_cap);

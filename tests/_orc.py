@@ -148,7 +148,7 @@ class AirOracle:
         bad = self.lib.orc_check_constraints(C.byref(self.chips[cid]), _ptr(main), _ptr(prep), log_n, _ptr(pubs), C.byref(bc), C.byref(br))
         return bad, bc.value, br.value
 
-    def logup_unbalanced(self, chips, pubs=None):
+    def logup_unbalanced(self, chips, pubs=None, extra=()):
         """chips: list of dict(chip_id, main, prep) with one `pubs`, or a list of (chips, pubs) groups
         (one per shard; the multiset is balanced across all of them).  Returns (count, first offending record)."""
         groups = [(chips, pubs)] if pubs is not None else chips
@@ -159,6 +159,10 @@ class AirOracle:
                 main, prep = self._arr(ch["main"]), self._arr(ch["prep"])
                 log_n = int(ch["main"].shape[1]).bit_length() - 1
                 self.lib.orc_multiset_add_chip(ms, C.byref(self.chips[ch["chip_id"]]), _ptr(main), _ptr(prep), log_n, _ptr(gp))
+        self.lib.orc_multiset_add_tuple.argtypes = [C.c_void_p, C.c_uint32, u32p, C.c_uint32, C.c_int, C.c_uint32]
+        for bus, vals, sign, mult in extra:   # explicit tuples: (bus, values, +1 send / -1 receive, multiplicity)
+            v = self._arr(vals)
+            self.lib.orc_multiset_add_tuple(ms, bus, _ptr(v), len(vals), sign, mult)
         out = np.zeros(64, np.uint32)
         n = self.lib.orc_multiset_unbalanced(ms, _ptr(out), out.size)
         self.lib.orc_multiset_free(ms)

@@ -5,18 +5,25 @@ multi-limb multiply-accumulate over 384-bit operands, whose instruction mix
 the reference's finalization guest."""
 import struct
 
-from tools.rvasm import Asm, SYS_HINT_LEN, SYS_HINT_READ, SYS_WRITE
+from tools.rvasm import Asm, SYS_COMMIT, SYS_HINT_LEN, SYS_HINT_READ, SYS_WRITE
 
 M32 = 0xFFFFFFFF
 HEAP = 0x00400000
 
 
 def _write_pv(a, ptr_reg, nbytes):
-    a.li("a0", 3)
-    a.mv("a1", ptr_reg)
-    a.li("a2", nbytes)
-    a.li("t0", SYS_WRITE)
+    """commit nbytes/4 words starting at ptr_reg as public values (one COMMIT ecall per word)"""
+    assert nbytes % 4 == 0
+    lab = f"commit_{len(a.items)}"
+    a.mv("s8", ptr_reg)
+    a.li("s9", nbytes // 4)
+    a.label(lab)
+    a.lw("a0", "s8", 0)
+    a.li("t0", SYS_COMMIT)
     a.ecall()
+    a.addi("s8", "s8", 4)
+    a.addi("s9", "s9", -1)
+    a.bne("s9", "zero", lab)
 
 
 def arith():

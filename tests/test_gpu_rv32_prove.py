@@ -38,13 +38,12 @@ def test_arith_guest_proof_verifies(gpu):
     assert ec == 0 and pv == want and rep["exit_code"] == 0
     # same input -> same proof bytes
     assert gpu.prove_core(pk)[0] == proof
-    # tampering with the container header or the shard proof is rejected.  (The public-value
-    # BYTES of the container are not yet bound to the proof — COMMIT digest binding is the
-    # next step, see DESIGN.md "Known gaps" — so they are excluded here.)
+    # tampering anywhere is rejected: container header, the public-value bytes (bound through the
+    # COMMIT bus whose receiving side the verifier supplies), and the shard proofs
     words = np.frombuffer(proof, dtype=np.uint32).copy()
     rng = np.random.default_rng(3)
     body = 4 + (len(want) + 3) // 4
-    for pos in [1, 2, 3, body, body + 1] + list(rng.integers(body + 1, len(words), 20)):
+    for pos in [1, 2, 3, 4, 5, body - 1, body, body + 1] + list(rng.integers(4, len(words), 20)):
         w = words.copy()
         w[pos] = (int(w[pos]) + 1) % 2013265921
         assert not capi.verify(vk, w.tobytes(), Q, POW)[0], f"tampered word {pos} accepted"

@@ -28,7 +28,11 @@ def check_traces(air, elf, stdin=(), log_shard=0):
         assert (len(chips) == 5) == (shard + 1 == n_shards)
         groups.append((chips, pubs))
         shard += 1
-    n, first = air.logup_unbalanced(groups)
+    # the verifier supplies the receiving side of the public-values bus (bus 5): (index, 4 bytes) per committed word
+    pv = capi.execute(elf, stdin)[2]
+    extra = [(5, [k] + list(pv[4 * k:4 * k + 4]), -1, 1) for k in range(len(pv) // 4)]
+    assert groups[-1][1][6] == len(pv) // 4 and groups[0][1][5] == 0
+    n, first = air.logup_unbalanced(groups, extra=extra)
     assert n == 0, f"{n} unbalanced LogUp tuples, first (bus, arity, mult, values...) = {first}"
     for a, b in zip(groups, groups[1:]):
         assert a[1][1] == b[1][0], "shards do not chain"
@@ -100,5 +104,11 @@ def test_tampered_trace_is_caught_by_oracle(air):
     byte = next(c for c in chips if air.chip(c["chip_id"]).name == b"byte")
     b2 = dict(byte, main=byte["main"].copy())
     b2["main"][5, 0] += 1
-    n, _ = air.logup_unbalanced([b2 if c is byte else c for c in chips], pubs)
+    pv = capi.execute(elf)[2]
+    extra = [(5, [k] + list(pv[4 * k:4 * k + 4]), -1, 1) for k in range(len(pv) // 4)]
+    assert air.logup_unbalanced(chips, pubs, extra=extra)[0] == 0
+    n, _ = air.logup_unbalanced([b2 if c is byte else c for c in chips], pubs, extra=extra)
     assert n == 1
+    # a wrong claimed public value unbalances the public-values bus
+    bad = [(b, v if i else [v[0], (v[1] + 1) % 256] + v[2:], s_, m) for i, (b, v, s_, m) in enumerate(extra)]
+    assert air.logup_unbalanced(chips, pubs, extra=bad)[0] == 2

@@ -29,7 +29,8 @@ supplied, hence trusted and mutually exclusive) selector.
 """
 from .dsl import Chip, Expr, Machine, esum, word
 
-BUSES = {"program": 1, "byte": 2, "mem": 3, "image": 4}
+BUSES = {"program": 1, "byte": 2, "mem": 3, "image": 4, "pv": 5}
+SYS_COMMIT = 0x10
 
 # byte-table opcodes
 B_AND, B_OR, B_XOR, B_LTU, B_MSB, B_RANGE, B_U16 = 1, 2, 3, 4, 5, 6, 7
@@ -43,8 +44,8 @@ FLAGS = [
 # instruction tuple on the program bus: pc, rd, rs1, rs2, imm[4], off[4], tgt, flags...
 N_INSTR_FIELDS = 1 + 3 + 4 + 4 + 1 + len(FLAGS)
 
-PUB_START_PC, PUB_NEXT_PC, PUB_EXIT_CODE, PUB_SHARD, PUB_IS_LAST = 0, 1, 2, 3, 4
-N_PUB = 5
+PUB_START_PC, PUB_NEXT_PC, PUB_EXIT_CODE, PUB_SHARD, PUB_IS_LAST, PUB_PV_START, PUB_PV_END = 0, 1, 2, 3, 4, 5, 6
+N_PUB = 7
 UNION_W = 21
 
 
@@ -90,6 +91,7 @@ def build_cpu():
     pa_prev = ch.cols("pa_prev", 4)
     pa_ts, pa_lo, pa_hi = ch.col("pa_ts"), ch.col("pa_lo"), ch.col("pa_hi")
     U = ch.cols("u", UNION_W)
+    pv_idx, commit_m = ch.col("pv_idx"), ch.col("commit_m")
 
     # ---------------- row bookkeeping
     ch.assert_bool(is_real)
@@ -243,6 +245,18 @@ def build_cpu():
     ch.assert_zero(ec * (word(b) * id_inv - (1 - is_halt)))
     ch.assert_zero(ec * (next_pc - (1 - is_halt) * (pc + 4)))
     ch.assert_zero(ec * (is_halt * (word(c) - ch.pub(PUB_EXIT_CODE))))
+    # COMMIT (id 0x10, a0 = word): the k-th committed word of the execution is a public value.  The row
+    # sends (k, bytes of a0) on the "pv" bus; the VERIFIER supplies the receiving side from the claimed
+    # public values, so they are bound to the proof.  pv_idx counts the words committed before this row.
+    is_commit, cm_inv = U[2], U[3]
+    ch.assert_zero(ec * (is_commit * (is_commit - 1)))
+    ch.assert_zero(ec * (is_commit * (word(b) - SYS_COMMIT)))
+    ch.assert_zero(ec * ((word(b) - SYS_COMMIT) * cm_inv - (1 - is_commit)))
+    ch.assert_zero(commit_m - ec * is_commit)
+    ch.assert_eq(pv_idx, ch.pub(PUB_PV_START), "first")
+    ch.assert_zero(pv_idx.next() - pv_idx - commit_m, "trans")
+    ch.assert_zero(pv_idx + commit_m - ch.pub(PUB_PV_END), "last")
+    ch.send("pv", [pv_idx] + c, commit_m)
     return ch
 
 
