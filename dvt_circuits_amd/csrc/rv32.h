@@ -12,8 +12,8 @@
 //     32-bit word to the public values, which the proof binds), 0x1A COMMIT_DEFERRED_PROOFS
 //     (no-op), 0xF0 HINT_LEN (-> t0), 0xF1 HINT_READ(ptr,len).  WRITE is not part of the statement.
 //     stdin is a list of byte buffers (SP1Stdin::write, src/main.rs:434-437).
-//   - instructions without a chip yet (shifts, mulh/mulhsu, div/rem, sub-word
-//     loads/stores) execute, but a program that retires one cannot be proven:
+//   - instructions without a chip yet (shifts, mulh/mulhsu, div/rem) execute, but a
+//     program that retires one cannot be proven:
 //     prove returns DVT_ERR_UNSUPPORTED.
 #pragma once
 #include <cstdint>
@@ -29,7 +29,8 @@ namespace rv32 {
 // flag bit positions, in the FLAGS order of tools/airgen/rv32.py
 enum Flag : uint32_t {
     F_RD_EN, F_RS1_EN, F_RS2_EN, F_IMM_C, F_ADD, F_SUB, F_AND, F_OR, F_XOR, F_SLT, F_SLTU, F_MUL, F_MULHU,
-    F_LUI, F_JAL, F_JALR, F_BEQ, F_BNE, F_BLT, F_BGE, F_BLTU, F_BGEU, F_LW, F_SW, F_ECALL, N_FLAGS
+    F_LUI, F_JAL, F_JALR, F_BEQ, F_BNE, F_BLT, F_BGE, F_BLTU, F_BGEU, F_LW, F_SW, F_ECALL,
+    F_LB, F_LBU, F_LH, F_LHU, F_SB, F_SH, N_FLAGS
 };
 constexpr uint32_t B_AND = 1, B_OR = 2, B_XOR = 3, B_LTU = 4, B_MSB = 5, B_RANGE = 6, B_U16 = 7;
 constexpr int N_BYTE_OPS = 7;  // multiplicity columns of the byte chip, in this order: and or xor ltu msb range u16
@@ -191,7 +192,7 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
         for (int k = 0; k < 8; k++) s.byte(B_U16 - 1, pcarry[k]);
         uint64_t pr = (uint64_t)b * c;
         for (int k = 0; k < 4; k++) s.byte(B_RANGE - 1, (((uint32_t)(pr >> (16 * k)) & 0xff) << 8) | ((uint32_t)(pr >> (16 * k + 8)) & 0xff));
-    } else if (F(F_LW) | F(F_SW) | F(F_JALR)) {
+    } else if (F(F_LW) | F(F_SW) | F(F_JALR) | F(F_LB) | F(F_LBU) | F(F_LH) | F(F_LHU) | F(F_SB) | F(F_SH)) {
         uint32_t sum = b + in.off, cin = 0;
         for (int i = 0; i < 4; i++) {
             uint32_t t = B(b, i) + B(in.off, i) + cin;
@@ -211,6 +212,14 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
             s.put(U + 18, m_hi); s.put(U + 19, r.m_sh); s.put(U + 20, r.m_sh == shard);
             s.byte(B_U16 - 1, d & 0xffff);
             s.byte(B_AND - 1, (B(sum, 0) << 8) | 3);
+            const uint32_t o = sum & 3;
+            if (o) s.put(U + 20 + o, 1);  // u[21..23]: one-hot of offsets 1..3
+            if (F(F_LB) | F(F_LH)) {
+                const uint32_t sbyte = F(F_LB) ? B(a, 0) : B(a, 1);
+                s.put(U + 24, sbyte);
+                s.put(U + 25, sbyte >> 7);
+                s.byte(B_MSB - 1, sbyte << 8);
+            }
         }
     } else if (F(F_ECALL)) {
         uint32_t idc = b % P;

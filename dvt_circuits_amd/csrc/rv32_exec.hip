@@ -42,14 +42,18 @@ static Instr decode(uint32_t w, uint32_t pc) {
         set_rs1(); set_rs2(); in.tgt = pc + imm_b; in.flags |= FL(map[f3]);
         break;
     }
-    case 0x03:
+    case 0x03: {
         set_rd(); set_rs1(); in.off = imm_i;
-        if (f3 == 2) in.flags |= FL(F_LW); else in.supported = 0;
+        static const int map[8] = {F_LB, F_LH, F_LW, -1, F_LBU, F_LHU, -1, -1};
+        if (map[f3] < 0) in.supported = 0; else in.flags |= FL(map[f3]);
         break;
-    case 0x23:
+    }
+    case 0x23: {
         set_rs1(); set_rs2(); in.off = imm_s;
-        if (f3 == 2) in.flags |= FL(F_SW); else in.supported = 0;
+        static const int map[8] = {F_SB, F_SH, F_SW, -1, -1, -1, -1, -1};
+        if (map[f3] < 0) in.supported = 0; else in.flags |= FL(map[f3]);
         break;
+    }
     case 0x13: {
         set_rd(); set_rs1(); in.imm = imm_i; in.flags |= FL(F_IMM_C);
         static const int map[8] = {F_ADD, -1, F_SLT, F_SLTU, F_XOR, -1, F_OR, F_AND};
@@ -249,16 +253,25 @@ void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin
             bool t = (fl & FL(F_BEQ)) ? b == c : (fl & FL(F_BNE)) ? b != c : (fl & FL(F_BLT)) ? (int32_t)b < (int32_t)c
                    : (fl & FL(F_BGE)) ? (int32_t)b >= (int32_t)c : (fl & FL(F_BLTU)) ? b < c : b >= c;
             if (t) next_pc = in.tgt;
-        } else if (fl & (FL(F_LW) | FL(F_SW))) {
-            uint32_t addr = b + in.off;
+        } else if (fl & (FL(F_LW) | FL(F_SW) | FL(F_LB) | FL(F_LBU) | FL(F_LH) | FL(F_LHU) | FL(F_SB) | FL(F_SH))) {
+            const uint32_t addr = b + in.off;
             if (addr < 32 || addr >= ADDR_LIMIT) { trap("memory access out of range"); return; }
-            if (addr & 3) { trap("misaligned word access"); return; }
-            Cell &cell = mem.at(addr);
+            if ((fl & (FL(F_LW) | FL(F_SW))) && (addr & 3)) { trap("misaligned word access"); return; }
+            if ((fl & (FL(F_LH) | FL(F_LHU) | FL(F_SH))) && (addr & 1)) { trap("misaligned halfword access"); return; }
+            Cell &cell = mem.at(addr & ~3u);
             if (!cell.touched) { cell.touched = 1; cell.init = cell.val; }
             rec.m_prev = cell.val;
             rec.m_ts = cell.ts;
             rec.m_sh = cell.sh;
-            if (fl & FL(F_SW)) cell.val = c; else a = cell.val;
+            const uint32_t sh8 = 8 * (addr & 3);
+            if (fl & FL(F_SW)) cell.val = c;
+            else if (fl & FL(F_SB)) cell.val = (cell.val & ~(0xffu << sh8)) | ((c & 0xff) << sh8);
+            else if (fl & FL(F_SH)) cell.val = (cell.val & ~(0xffffu << sh8)) | ((c & 0xffff) << sh8);
+            else if (fl & FL(F_LW)) a = cell.val;
+            else if (fl & FL(F_LB)) a = sext((cell.val >> sh8) & 0xff, 8);
+            else if (fl & FL(F_LBU)) a = (cell.val >> sh8) & 0xff;
+            else if (fl & FL(F_LH)) a = sext((cell.val >> sh8) & 0xffff, 16);
+            else a = (cell.val >> sh8) & 0xffff;
             rec.m_val = cell.val;
             cell.ts = clk + 2;
             cell.sh = shard;

@@ -195,3 +195,48 @@ def traps():
     a.lw("a4", "a3", 1)            # misaligned
     a.halt(0)
     return a.elf()
+
+
+def subword():
+    """LB/LBU/LH/LHU at every offset of sign-critical words, SB/SH patches; results are committed."""
+    words = [0x80FF7F01, 0x12B4E6F8, 0x00000080]
+    a = Asm()
+    src = a.dword("src", words)
+    dst = a.dword("dst", [0x11223344, 0x55667788, 0x99AABBCC])
+    out = a.dword("out", [0] * 64)
+    a.li("s0", out)
+    a.li("s1", src)
+    exp = []
+    sx = lambda v, b: (v - (1 << b)) & M32 if v >> (b - 1) else v
+    for wi, w in enumerate(words):
+        for o in range(4):
+            byte = (w >> (8 * o)) & 0xFF
+            for name, want in (("lb", sx(byte, 8)), ("lbu", byte)):
+                getattr(a, name)("a5", "s1", 4 * wi + o)
+                a.sw("a5", "s0", 0)
+                a.addi("s0", "s0", 4)
+                exp.append(want)
+        for o in (0, 2):
+            half = (w >> (8 * o)) & 0xFFFF
+            for name, want in (("lh", sx(half, 16)), ("lhu", half)):
+                getattr(a, name)("a5", "s1", 4 * wi + o)
+                a.sw("a5", "s0", 0)
+                a.addi("s0", "s0", 4)
+                exp.append(want)
+    a.li("s2", dst)
+    a.li("a3", 0xDEADBEEF)
+    mem = [0x11223344, 0x55667788, 0x99AABBCC]
+    for (op, off, nbytes) in (("sb", 1, 1), ("sb", 3, 1), ("sh", 4, 2), ("sh", 6, 2), ("sb", 8, 1), ("sh", 10, 2)):
+        getattr(a, op)("a3", "s2", off)
+        wi, o = off // 4, off % 4
+        mask = ((1 << (8 * nbytes)) - 1) << (8 * o)
+        mem[wi] = (mem[wi] & ~mask & M32) | ((0xDEADBEEF << (8 * o)) & mask)
+    for wi in range(3):
+        a.lw("a5", "s2", 4 * wi)
+        a.sw("a5", "s0", 0)
+        a.addi("s0", "s0", 4)
+        exp.append(mem[wi])
+    a.li("s1", out)
+    _write_pv(a, "s1", 4 * len(exp))
+    a.halt(0)
+    return a.elf(), b"".join(struct.pack("<I", v) for v in exp)

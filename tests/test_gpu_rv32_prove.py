@@ -74,6 +74,17 @@ def test_bignum_and_hint_guests(gpu):
     gpu.pk_free(pk)
 
 
+def test_subword_guest_proof(gpu):
+    from dvt_circuits_amd import capi
+
+    elf, want = guests.subword()
+    pk, vk = gpu.setup(elf)
+    proof, rep = gpu.prove_core(pk)
+    ok, ec, pv, why = capi.verify(vk, proof, Q, POW)
+    assert ok and pv == want, why
+    gpu.pk_free(pk)
+
+
 def test_multi_shard_proof(gpu):
     """one execution cut into 2^10-cycle shards: the shards verify only together (common LogUp
     challenges, memory bus balanced across shards, pc / shard-index chaining)"""

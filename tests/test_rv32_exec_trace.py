@@ -66,6 +66,15 @@ def test_multi_shard_traces(air, log_shard):
     check_traces(air, elf2, [struct.pack("<8I", *range(8))], log_shard=4)
 
 
+def test_subword_guest(air):
+    elf, want = guests.subword()
+    rc, rep, pv, err = capi.execute(elf)
+    assert rc == 0 and not rep["unprovable"], err
+    assert pv == want
+    check_traces(air, elf)
+    check_traces(air, elf, log_shard=6)
+
+
 def test_hint_guest(air):
     elf = guests.hint_sum()
     data = struct.pack("<8I", *range(100, 108))

@@ -40,13 +40,14 @@ FLAGS = [
     "is_add", "is_sub", "is_and", "is_or", "is_xor", "is_slt", "is_sltu", "is_mul", "is_mulhu",
     "is_lui", "is_jal", "is_jalr", "is_beq", "is_bne", "is_blt", "is_bge", "is_bltu", "is_bgeu",
     "is_lw", "is_sw", "is_ecall",
+    "is_lb", "is_lbu", "is_lh", "is_lhu", "is_sb", "is_sh",
 ]
 # instruction tuple on the program bus: pc, rd, rs1, rs2, imm[4], off[4], tgt, flags...
 N_INSTR_FIELDS = 1 + 3 + 4 + 4 + 1 + len(FLAGS)
 
 PUB_START_PC, PUB_NEXT_PC, PUB_EXIT_CODE, PUB_SHARD, PUB_IS_LAST, PUB_PV_START, PUB_PV_END = 0, 1, 2, 3, 4, 5, 6
 N_PUB = 7
-UNION_W = 21
+UNION_W = 26
 
 
 def build_program():
@@ -133,7 +134,8 @@ def build_cpu():
     sel_signed = F["is_slt"] + F["is_blt"] + F["is_bge"]
     sel_cmp = F["is_slt"] + F["is_sltu"] + sel_branch
     sel_mul = F["is_mul"] + F["is_mulhu"]
-    sel_mem = F["is_lw"] + F["is_sw"]
+    sel_loadsub = F["is_lb"] + F["is_lbu"] + F["is_lh"] + F["is_lhu"]
+    sel_mem = F["is_lw"] + F["is_sw"] + sel_loadsub + F["is_sb"] + F["is_sh"]
     sel_adder = sel_mem + F["is_jalr"]
 
     # ADD / SUB : u[0..3] = carries
@@ -211,19 +213,49 @@ def build_cpu():
     jl = U[8]
     ch.assert_zero(F["is_jalr"] * (jl * (jl - 1)))
     ch.assert_zero(F["is_jalr"] * (next_pc - word(s) + jl))
-    # LW / SW: u[8..11] memory value after, u[12..15] before, u[16] prev ts, u[17] lo, u[18] hi
+    # loads / stores: u[8..11] memory word after, u[12..15] before, u[16] prev clk, u[17] lo, u[18] hi,
+    # u[19] prev shard, u[20] same-shard flag, u[21..23] byte-offset one-hot (offset 0 = none set),
+    # u[24] the byte whose sign extends a sub-word load, u[25] its sign bit.
+    # The access always moves the whole aligned word on the memory bus; sub-word forms select / patch bytes.
     mv, mp, m_ts, m_lo, m_hi, m_sh, m_same = U[8:12], U[12:16], U[16], U[17], U[18], U[19], U[20]
-    ch.send("byte", [B_AND, 0, s[0], 3], sel_mem)             # word aligned
-    ch.receive("mem", [word(s)] + mp + [m_sh, m_ts], sel_mem)
-    ch.send("mem", [word(s)] + mv + [shard, clk + 2], sel_mem)
+    o1, o2, o3, sb, sgn = U[21], U[22], U[23], U[24], U[25]
+    o0 = 1 - o1 - o2 - o3
+    oh = [o0, o1, o2, o3]
+    o_val = o1 + 2 * o2 + 3 * o3
+    for x in (o1, o2, o3):
+        ch.assert_zero(sel_mem * (x * (x - 1)))
+    ch.assert_zero(sel_mem * ((o1 + o2 + o3) * (o1 + o2 + o3 - 1)))
+    ch.send("byte", [B_AND, o_val, s[0], 3], sel_mem)         # offset = low two address bits
+    ch.assert_zero((F["is_lw"] + F["is_sw"]) * (o1 + o2 + o3))                      # word access: aligned
+    ch.assert_zero((F["is_lh"] + F["is_lhu"] + F["is_sh"]) * (o1 + o3))              # halfword access: even
+    maddr = word(s) - o_val
+    ch.receive("mem", [maddr] + mp + [m_sh, m_ts], sel_mem)
+    ch.send("mem", [maddr] + mv + [shard, clk + 2], sel_mem)
     ch.assert_zero(sel_mem * (m_same * (m_same - 1)))
     ch.assert_zero(sel_mem * (m_same * (shard - m_sh)))
     ch.assert_zero(sel_mem * (m_same * (clk + 2 - m_ts - 1) + (1 - m_same) * (shard - m_sh - 1) - m_lo - 65536 * m_hi))
     ch.send("byte", [B_U16, 0, m_lo, 0], sel_mem)
+    sel_load = F["is_lw"] + sel_loadsub
     for i in range(4):
         ch.assert_zero(F["is_lw"] * (a[i] - mv[i]))
-        ch.assert_zero(F["is_lw"] * (mp[i] - mv[i]))
+        ch.assert_zero(sel_load * (mp[i] - mv[i]))                                   # loads leave memory unchanged
         ch.assert_zero(F["is_sw"] * (mv[i] - c[i]))
+        ch.assert_zero(F["is_sb"] * (mv[i] - mp[i] - oh[i] * (c[0] - mp[i])))        # patch byte `offset`
+    ch.assert_zero(F["is_sh"] * (mv[0] - mp[0] - o0 * (c[0] - mp[0])))
+    ch.assert_zero(F["is_sh"] * (mv[1] - mp[1] - o0 * (c[1] - mp[1])))
+    ch.assert_zero(F["is_sh"] * (mv[2] - mp[2] - o2 * (c[0] - mp[2])))
+    ch.assert_zero(F["is_sh"] * (mv[3] - mp[3] - o2 * (c[1] - mp[3])))
+    sel_byte, sel_half, sel_sext = F["is_lb"] + F["is_lbu"], F["is_lh"] + F["is_lhu"], F["is_lb"] + F["is_lh"]
+    ch.assert_zero(sel_byte * (a[0] - esum(oh[i] * mp[i] for i in range(4))))
+    ch.assert_zero(sel_half * (a[0] - o0 * mp[0] - o2 * mp[2]))
+    ch.assert_zero(sel_half * (a[1] - o0 * mp[1] - o2 * mp[3]))
+    ch.assert_zero(F["is_lb"] * (sb - a[0]))
+    ch.assert_zero(F["is_lh"] * (sb - a[1]))
+    ch.send("byte", [B_MSB, sgn, sb, 0], sel_sext)
+    ch.assert_zero((F["is_lbu"] + F["is_lhu"]) * sgn)
+    ch.assert_zero(sel_byte * (a[1] - 255 * sgn))
+    for i in (2, 3):
+        ch.assert_zero(sel_loadsub * (a[i] - 255 * sgn))
     # the 8-bit high limbs of the four timestamp differences, two per lookup
     ch.send("byte", [B_RANGE, 0, pb_hi, pc_hi], is_real)
     ch.send("byte", [B_RANGE, 0, pa_hi, m_hi], is_real)      # (u[16..19] belong to the memory family only)
