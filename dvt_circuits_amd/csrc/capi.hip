@@ -417,9 +417,9 @@ struct ShardJob {
     size_t n_recs = 0;
     uint32_t pv_end = 0;
     rv32::CycleRec *d_recs = nullptr;
-    uint32_t log_n[5] = {0, 0, 0, 0, 0};
-    bool present[5] = {false, false, false, false, false};
-    uint32_t *d_aux[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // main traces except cpu
+    uint32_t log_n[rv32::N_CHIPS] = {};
+    bool present[rv32::N_CHIPS] = {};
+    uint32_t *d_aux[rv32::N_CHIPS] = {};  // main traces except cpu
     std::vector<Fp> pubs;
     MainCache cache;  // phase-1 LDEs + tree of the main traces, consumed by phase 2
 };
@@ -784,11 +784,12 @@ int dvt_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, size_t pr
             if (pubv[5] != (i ? sps[i - 1].public_values[6].canonical() : 0u)) return reject(DVT_ERR_REJECTED, "public-value counters do not chain");
             if (pubv[6] < pubv[5]) return reject(DVT_ERR_REJECTED, "public-value counter decreases");
             if (last && (pvl % 4 || pubv[6] != pvl / 4)) return reject(DVT_ERR_REJECTED, "number of committed public-value words does not match");
-            // chip set: every chip in the last shard, all but mem_init in the others
-            const size_t want = last ? (size_t)machine_rv32()->n_chips : (size_t)machine_rv32()->n_chips - 1;
-            if (sp.chips.size() != want) return reject(DVT_ERR_REJECTED, "unexpected chip set in shard");
-            for (auto &c : sp.chips)
-                if (!last && c.chip_id == RV32_CHIP_MEM_INIT) return reject(DVT_ERR_REJECTED, "mem_init outside the last shard");
+            // chip set: program, byte, cpu, mem_image always; mem_init in the last shard only; shift when the shard shifts
+            bool have[rv32::N_CHIPS] = {};
+            for (auto &c : sp.chips) have[c.chip_id] = true;
+            for (int c : {RV32_CHIP_PROGRAM, RV32_CHIP_BYTE, RV32_CHIP_CPU, RV32_CHIP_MEM_IMAGE})
+                if (!have[c]) return reject(DVT_ERR_REJECTED, "a mandatory chip is missing from a shard");
+            if (have[RV32_CHIP_MEM_INIT] != last) return reject(DVT_ERR_REJECTED, "mem_init must be part of exactly the last shard");
             for (int k = 0; k < 8; k++) headers[i * HEADER_WORDS + k] = sp.main_root.d[k].canonical();
             for (uint32_t k = 0; k < N_PUB; k++) headers[i * HEADER_WORDS + 8 + k] = pubv[k];
         }
@@ -874,7 +875,7 @@ int dvt_rv32_debug_device_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *j, si
     HIP_TRY(p, hipStreamSynchronize(p->eng.stream));
     const MachineDesc *m = machine_rv32();
     rv32::HostTraces T;
-    for (int c = 0; c < 5; c++) T.present[c] = false;
+    for (int c = 0; c < rv32::N_CHIPS; c++) T.present[c] = false;
     for (auto &t : traces) {
         size_t words = (size_t)m->chips[t.chip_id].main_w << t.log_n;
         T.present[t.chip_id] = true;

@@ -12,7 +12,7 @@
 //     32-bit word to the public values, which the proof binds), 0x1A COMMIT_DEFERRED_PROOFS
 //     (no-op), 0xF0 HINT_LEN (-> t0), 0xF1 HINT_READ(ptr,len).  WRITE is not part of the statement.
 //     stdin is a list of byte buffers (SP1Stdin::write, src/main.rs:434-437).
-//   - instructions without a chip yet (shifts, mulh/mulhsu, div/rem) execute, but a
+//   - instructions without a chip yet (mulh/mulhsu, div/rem) execute, but a
 //     program that retires one cannot be proven:
 //     prove returns DVT_ERR_UNSUPPORTED.
 #pragma once
@@ -30,16 +30,19 @@ namespace rv32 {
 enum Flag : uint32_t {
     F_RD_EN, F_RS1_EN, F_RS2_EN, F_IMM_C, F_ADD, F_SUB, F_AND, F_OR, F_XOR, F_SLT, F_SLTU, F_MUL, F_MULHU,
     F_LUI, F_JAL, F_JALR, F_BEQ, F_BNE, F_BLT, F_BGE, F_BLTU, F_BGEU, F_LW, F_SW, F_ECALL,
-    F_LB, F_LBU, F_LH, F_LHU, F_SB, F_SH, N_FLAGS
+    F_LB, F_LBU, F_LH, F_LHU, F_SB, F_SH, F_ALU, N_FLAGS
 };
 constexpr uint32_t B_AND = 1, B_OR = 2, B_XOR = 3, B_LTU = 4, B_MSB = 5, B_RANGE = 6, B_U16 = 7;
 constexpr int N_BYTE_OPS = 7;  // multiplicity columns of the byte chip, in this order: and or xor ltu msb range u16
 constexpr uint32_t ADDR_LIMIT = 1u << 30;
 constexpr uint32_t SYS_COMMIT = 0x10;
+constexpr uint32_t ALU_SLL = 1, ALU_SRL = 2, ALU_SRA = 3;  // alu-bus opcodes (chips outside the cpu chip)
+constexpr int N_CHIPS = 6;                                 // program, byte, cpu, mem_image, mem_init, shift
 constexpr uint32_t N_PUBLIC = 7;  // start_pc, next_pc, exit_code, shard, is_last, pv_start, pv_end
 
 struct Instr {
     uint32_t pc, rd, rs1, rs2, imm, off, tgt, flags;
+    uint32_t alu_op;  // for F_ALU instructions: which chip / operation receives (a, b, c)
     uint32_t raw;
     uint8_t supported;  // has a chip (otherwise executes only)
 };
@@ -66,8 +69,13 @@ struct MemInitRow {
     uint32_t addr, v, f, fts, fsh, is_img;
 };
 
+struct AluEvent {
+    uint32_t op, a, b, c;
+};
+
 // One shard = up to 2^log_shard consecutive cycles; shards are numbered from 1.
 struct ShardRec {
+    std::vector<AluEvent> alu;   // instructions of this shard proven by chips outside the cpu chip
     uint32_t index = 0, start_pc = 0, next_pc = 0;
     uint32_t pv_start = 0, pv_end = 0;   // committed public-value words before / after this shard
     std::vector<CycleRec> recs;
@@ -115,6 +123,7 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
         s.put(RV32_CPU_pa_prev_0 + i, B(r.pa_prev, i));
     }
     s.put(RV32_CPU_tgt, in.tgt);
+    s.put(RV32_CPU_alu_op, in.alu_op);
     s.put(RV32_CPU_pv_idx, r.pv_idx);
     for (uint32_t k = 0; k < N_FLAGS; k++) s.put(RV32_CPU_rd_en + k, F(k));
     s.prog(r.idx);
@@ -241,15 +250,15 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
 // Host-side trace bundle of one shard (canonical, column-major), for the debug C-ABI and tests.
 // present[c] = chip c is part of this shard (mem_init only in the last one).
 struct HostTraces {
-    uint32_t log_n[5];
-    bool present[5];
-    std::vector<uint32_t> main[5];
+    uint32_t log_n[N_CHIPS];
+    bool present[N_CHIPS];
+    std::vector<uint32_t> main[N_CHIPS];
     std::vector<uint32_t> pubs;   // start_pc, next_pc, exit_code, shard, is_last, pv_start, pv_end
 };
 // preprocessed traces (program, byte, mem_image) for setup
 struct HostPrep {
-    uint32_t log_n[5];
-    std::vector<uint32_t> prep[5];
+    uint32_t log_n[N_CHIPS];
+    std::vector<uint32_t> prep[N_CHIPS];
 };
 void build_prep(const Program &prog, HostPrep *out);
 bool build_traces_host(const Program &prog, const ExecResult &res, size_t shard_pos, const HostPrep &prep, HostTraces *out, std::string *err);

@@ -57,13 +57,23 @@ static Instr decode(uint32_t w, uint32_t pc) {
     case 0x13: {
         set_rd(); set_rs1(); in.imm = imm_i; in.flags |= FL(F_IMM_C);
         static const int map[8] = {F_ADD, -1, F_SLT, F_SLTU, F_XOR, -1, F_OR, F_AND};
-        if (map[f3] < 0) { in.supported = 0; in.imm = rs2; } else in.flags |= FL(map[f3]);
+        if (map[f3] >= 0) in.flags |= FL(map[f3]);
+        else {  // SLLI / SRLI / SRAI: the shift chip, shift amount as the immediate operand
+            in.imm = rs2;
+            in.flags |= FL(F_ALU);
+            if (f3 == 1 && f7 == 0x00) in.alu_op = ALU_SLL;
+            else if (f3 == 5 && f7 == 0x00) in.alu_op = ALU_SRL;
+            else if (f3 == 5 && f7 == 0x20) in.alu_op = ALU_SRA;
+            else in.supported = 0;
+        }
         break;
     }
     case 0x33: {
         set_rd(); set_rs1(); set_rs2();
         int fam = -1;
-        if (f7 == 0x00) { static const int m0[8] = {F_ADD, -1, F_SLT, F_SLTU, F_XOR, -1, F_OR, F_AND}; fam = m0[f3]; }
+        if (f7 == 0x00 && (f3 == 1 || f3 == 5)) { fam = F_ALU; in.alu_op = f3 == 1 ? ALU_SLL : ALU_SRL; }
+        else if (f7 == 0x20 && f3 == 5) { fam = F_ALU; in.alu_op = ALU_SRA; }
+        else if (f7 == 0x00) { static const int m0[8] = {F_ADD, -1, F_SLT, F_SLTU, F_XOR, -1, F_OR, F_AND}; fam = m0[f3]; }
         else if (f7 == 0x20) { fam = f3 == 0 ? F_SUB : -1; }
         else if (f7 == 0x01) { fam = f3 == 0 ? F_MUL : f3 == 3 ? F_MULHU : -1; }
         if (fam < 0) in.supported = 0; else in.flags |= FL(fam);
@@ -243,6 +253,11 @@ void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin
         else if (fl & FL(F_MUL)) a = b * c;
         else if (fl & FL(F_MULHU)) a = (uint32_t)(((uint64_t)b * c) >> 32);
         else if (fl & FL(F_LUI)) a = in.imm;
+        else if (fl & FL(F_ALU)) {
+            const uint32_t sh = c & 31;
+            a = in.alu_op == ALU_SLL ? b << sh : in.alu_op == ALU_SRL ? b >> sh : (uint32_t)((int32_t)b >> sh);
+            if (trace) R.shards.back().alu.push_back(AluEvent{in.alu_op, a, b, c});
+        }
         else if (fl & FL(F_JAL)) { a = in.imm; next_pc = in.tgt; }
         else if (fl & FL(F_JALR)) {
             a = in.imm;
@@ -366,6 +381,7 @@ void build_prep(const Program &prog, HostPrep *out) {
         put(RV32_PROGRAM_P_pc, in.pc); put(RV32_PROGRAM_P_rd, in.rd); put(RV32_PROGRAM_P_rs1, in.rs1); put(RV32_PROGRAM_P_rs2, in.rs2);
         for (int i = 0; i < 4; i++) { put(RV32_PROGRAM_P_imm_0 + i, (in.imm >> (8 * i)) & 0xff); put(RV32_PROGRAM_P_off_0 + i, (in.off >> (8 * i)) & 0xff); }
         put(RV32_PROGRAM_P_tgt, in.tgt);
+        put(RV32_PROGRAM_P_alu_op, in.alu_op);
         for (uint32_t k = 0; k < N_FLAGS; k++) put(RV32_PROGRAM_P_rd_en + k, (in.flags >> k) & 1);
     }
     // byte table
@@ -421,7 +437,7 @@ bool build_aux_host(const Program &prog, const ExecResult &res, size_t shard_pos
     const bool last = shard_pos + 1 == res.shards.size();
     const uint32_t lc = ceil_log2(S.recs.size());
     if (lc > 22) { if (err) *err = "shard longer than 2^22 cycles"; return false; }
-    for (int c = 0; c < 5; c++) { T.present[c] = true; T.main[c].clear(); }
+    for (int c = 0; c < N_CHIPS; c++) { T.present[c] = true; T.main[c].clear(); }
     T.log_n[RV32_CHIP_CPU] = lc;
     std::vector<uint32_t> byte_mult((size_t)N_BYTE_OPS * 65536, 0);
     HostSink sink{nullptr, 0, 0, byte_mult.data(), nullptr};
@@ -453,6 +469,46 @@ bool build_aux_host(const Program &prog, const ExecResult &res, size_t shard_pos
                 sink.byte(B_RANGE - 1, (((m.v >> 16) & 0xff) << 8) | (m.v >> 24));
             }
             prev_addr = m.addr;
+        }
+    }
+    // shift chip: one row per SLL/SRL/SRA of this shard (absent when the shard does not shift)
+    T.present[RV32_CHIP_SHIFT] = !S.alu.empty();
+    T.log_n[RV32_CHIP_SHIFT] = 0;
+    if (!S.alu.empty()) {
+        const uint32_t ls = ceil_log2(S.alu.size());
+        const size_t ns = (size_t)1 << ls;
+        T.log_n[RV32_CHIP_SHIFT] = ls;
+        auto &H = T.main[RV32_CHIP_SHIFT];
+        H.assign((size_t)RV32_SHIFT_MAIN_W * ns, 0);
+        for (size_t r = 0; r < S.alu.size(); r++) {
+            const AluEvent &e = S.alu[r];
+            auto put = [&](int col, uint32_t v) { H[(size_t)col * ns + r] = v; };
+            auto B = [](uint32_t w, int i) -> uint32_t { return (w >> (8 * i)) & 0xffu; };
+            const uint32_t sh = e.c & 31, q = sh >> 3, rb = sh & 7, m = 1u << rb, mi = 1u << (8 - rb);
+            const bool left = e.op == ALU_SLL;
+            const uint32_t sgn = e.op == ALU_SRA ? e.b >> 31 : 0;
+            put(RV32_SHIFT_is_real, 1);
+            put(left ? RV32_SHIFT_is_sll : e.op == ALU_SRL ? RV32_SHIFT_is_srl : RV32_SHIFT_is_sra, 1);
+            put(RV32_SHIFT_sh, sh);
+            if (q) put(RV32_SHIFT_q_0 + q - 1, 1);
+            put(RV32_SHIFT_r_0 + rb, 1);
+            put(RV32_SHIFT_sgn, sgn);
+            uint32_t lo[4], hi[4];
+            for (int i = 0; i < 4; i++) {
+                put(RV32_SHIFT_a_0 + i, B(e.a, i)); put(RV32_SHIFT_b_0 + i, B(e.b, i)); put(RV32_SHIFT_c_0 + i, B(e.c, i));
+                if (left) { uint32_t pr = B(e.b, i) * m; lo[i] = pr & 0xff; hi[i] = pr >> 8; }
+                else { hi[i] = B(e.b, i) >> rb; lo[i] = B(e.b, i) & (m - 1); }
+                put(RV32_SHIFT_lo_0 + i, lo[i]); put(RV32_SHIFT_hi_0 + i, hi[i]);
+            }
+            for (int i = 0; i < 4; i++) {
+                uint32_t t = left ? lo[i] + (i ? hi[i - 1] : 0) : hi[i] + (i < 3 ? lo[i + 1] * mi : sgn * (256 - mi));
+                put(RV32_SHIFT_t_0 + i, t);
+                if (!left) sink.byte(B_LTU - 1, (lo[i] << 8) | m);
+            }
+            sink.byte(B_AND - 1, (B(e.c, 0) << 8) | 31);
+            sink.byte(B_RANGE - 1, (lo[0] << 8) | lo[1]); sink.byte(B_RANGE - 1, (lo[2] << 8) | lo[3]);
+            sink.byte(B_RANGE - 1, (hi[0] << 8) | hi[1]); sink.byte(B_RANGE - 1, (hi[2] << 8) | hi[3]);
+            if (e.op == ALU_SRA) sink.byte(B_MSB - 1, B(e.b, 3) << 8);
         }
     }
     const uint32_t lp = prep.log_n[RV32_CHIP_PROGRAM];

@@ -181,12 +181,46 @@ def exit_with(code):
     return a.elf()
 
 
-def uses_shift():
+def uses_unprovable():
+    """retires an instruction that executes but has no chip yet (DIV)"""
     a = Asm()
-    a.li("a3", 7)
-    a.slli("a3", "a3", 3)
+    a.li("a3", 77)
+    a.li("a4", 5)
+    a.div("a3", "a3", "a4")
     a.halt(0)
     return a.elf()
+
+
+def shifts():
+    """SLL/SRL/SRA (register and immediate forms) over sign-critical values and every class of shift amount"""
+    vals = [0x80000001, 0x7FFFFFFF, 0x12345678, 0xFFFFFFFF, 0x00000001, 0xF0F0F0F0]
+    amounts = [0, 1, 7, 8, 9, 15, 16, 24, 31, 32 + 3]     # (the last one checks that only the low 5 bits count)
+    a = Asm()
+    out = a.dword("out", [0] * (len(vals) * len(amounts) * 6 + 4))
+    a.li("s0", out)
+    exp = []
+    sx = lambda v: v - (1 << 32) if v >> 31 else v
+    for v in vals:
+        a.li("a3", v)
+        for sh in amounts:
+            a.li("a4", sh)
+            k = sh & 31
+            res = [("sll", (v << k) & M32), ("srl", v >> k), ("sra", (sx(v) >> k) & M32)]
+            for name, want in res:
+                getattr(a, name)("a5", "a3", "a4")
+                a.sw("a5", "s0", 0)
+                a.addi("s0", "s0", 4)
+                exp.append(want)
+            if sh < 32:
+                for name, want in (("slli", (v << k) & M32), ("srli", v >> k), ("srai", (sx(v) >> k) & M32)):
+                    getattr(a, name)("a5", "a3", sh)
+                    a.sw("a5", "s0", 0)
+                    a.addi("s0", "s0", 4)
+                    exp.append(want)
+    a.li("s1", out)
+    _write_pv(a, "s1", 4 * len(exp))
+    a.halt(0)
+    return a.elf(), b"".join(struct.pack("<I", v) for v in exp)
 
 
 def traps():

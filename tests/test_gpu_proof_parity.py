@@ -64,18 +64,18 @@ def test_toy_proof_bytes_equal_oracle(shape):
     p.close()
 
 
-@pytest.mark.parametrize("log_shard", [21, 8])
-def test_rv32_proof_bytes_equal_oracle(log_shard):
+@pytest.mark.parametrize("log_shard,which", [(21, "bignum"), (8, "bignum"), (9, "shifts")])
+def test_rv32_proof_bytes_equal_oracle(log_shard, which):
     from dvt_circuits_amd import capi
 
-    elf, want = guests.bignum(2, limbs=3)
+    elf, want = guests.bignum(2, limbs=3) if which == "bignum" else guests.shifts()
     p = capi.Prover('{"fri_queries": %d, "pow_bits": %d, "log_shard_size": %d}' % (Q, POW, log_shard))
     pk, vk = p.setup(elf)
     proof, rep = p.prove_core(pk)
     ec, pv, gpu_shards = split_container(proof)
     assert ec == 0 and pv == want
     cpu_shards = oracle_prove_execution(elf, (), log_shard)
-    assert len(gpu_shards) == len(cpu_shards) and (len(gpu_shards) > 1) == (log_shard < 9)
+    assert len(gpu_shards) == len(cpu_shards) and (len(gpu_shards) > 1) == (log_shard < 21)
     for i, (g, c) in enumerate(zip(gpu_shards, cpu_shards)):
         assert g == c, f"shard {i}: first differing word / lengths: {first_diff(g, c)}"
     assert capi.verify(vk, proof, Q, POW)[0]

@@ -74,10 +74,11 @@ def test_bignum_and_hint_guests(gpu):
     gpu.pk_free(pk)
 
 
-def test_subword_guest_proof(gpu):
+@pytest.mark.parametrize("which", ["subword", "shifts"])
+def test_subword_and_shift_guest_proofs(gpu, which):
     from dvt_circuits_amd import capi
 
-    elf, want = guests.subword()
+    elf, want = getattr(guests, which)()
     pk, vk = gpu.setup(elf)
     proof, rep = gpu.prove_core(pk)
     ok, ec, pv, why = capi.verify(vk, proof, Q, POW)
@@ -129,7 +130,7 @@ def test_error_classes(gpu):
         gpu.prove_core(pk)
     assert e.value.code == capi.DVT_ERR_GUEST
     gpu.pk_free(pk)
-    pk, _ = gpu.setup(guests.uses_shift())
+    pk, _ = gpu.setup(guests.uses_unprovable())
     with pytest.raises(capi.DvtError) as e:
         gpu.prove_core(pk)
     assert e.value.code == capi.DVT_ERR_UNSUPPORTED

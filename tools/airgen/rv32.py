@@ -10,6 +10,7 @@ Chips
   mem_image preprocessed initial memory image (registers = 0, ELF segments)
   mem_init  one row per initialised address, sorted: initial value at timestamp 0,
             final value/timestamp; image words are bound to mem_image
+  shift     SLL/SRL/SRA rows, fed by the cpu chip over the alu bus (only in shards that shift)
 
 Memory consistency is an offline-checking LogUp multiset over tuples
 (addr, byte0..3, timestamp): every access consumes the previous tuple of its
@@ -29,7 +30,8 @@ supplied, hence trusted and mutually exclusive) selector.
 """
 from .dsl import Chip, Expr, Machine, esum, word
 
-BUSES = {"program": 1, "byte": 2, "mem": 3, "image": 4, "pv": 5}
+BUSES = {"program": 1, "byte": 2, "mem": 3, "image": 4, "pv": 5, "alu": 6}
+ALU_SLL, ALU_SRL, ALU_SRA = 1, 2, 3
 SYS_COMMIT = 0x10
 
 # byte-table opcodes
@@ -41,9 +43,10 @@ FLAGS = [
     "is_lui", "is_jal", "is_jalr", "is_beq", "is_bne", "is_blt", "is_bge", "is_bltu", "is_bgeu",
     "is_lw", "is_sw", "is_ecall",
     "is_lb", "is_lbu", "is_lh", "is_lhu", "is_sb", "is_sh",
+    "is_alu",   # the result comes from another chip over the "alu" bus (alu_op selects it)
 ]
-# instruction tuple on the program bus: pc, rd, rs1, rs2, imm[4], off[4], tgt, flags...
-N_INSTR_FIELDS = 1 + 3 + 4 + 4 + 1 + len(FLAGS)
+# instruction tuple on the program bus: pc, rd, rs1, rs2, imm[4], off[4], tgt, alu_op, flags...
+N_INSTR_FIELDS = 1 + 3 + 4 + 4 + 1 + 1 + len(FLAGS)
 
 PUB_START_PC, PUB_NEXT_PC, PUB_EXIT_CODE, PUB_SHARD, PUB_IS_LAST, PUB_PV_START, PUB_PV_END = 0, 1, 2, 3, 4, 5, 6
 N_PUB = 7
@@ -53,7 +56,7 @@ UNION_W = 26
 def build_program():
     ch = Chip("program")
     fields = [ch.prep("pc"), ch.prep("rd"), ch.prep("rs1"), ch.prep("rs2")]
-    fields += ch.preps("imm", 4) + ch.preps("off", 4) + [ch.prep("tgt")]
+    fields += ch.preps("imm", 4) + ch.preps("off", 4) + [ch.prep("tgt"), ch.prep("alu_op")]
     fields += [ch.prep(f) for f in FLAGS]
     mult = ch.col("mult")
     ch.receive("program", fields, mult)
@@ -79,7 +82,7 @@ def build_cpu():
     ch = Chip("cpu")
     is_real, clk, pc, next_pc = ch.col("is_real"), ch.col("clk"), ch.col("pc"), ch.col("next_pc")
     rd, rs1, rs2 = ch.col("rd"), ch.col("rs1"), ch.col("rs2")
-    imm, off, tgt = ch.cols("imm", 4), ch.cols("off", 4), ch.col("tgt")
+    imm, off, tgt, alu_op = ch.cols("imm", 4), ch.cols("off", 4), ch.col("tgt"), ch.col("alu_op")
     F = {f: ch.col(f) for f in FLAGS}
     a, b, c = ch.cols("a", 4), ch.cols("b", 4), ch.cols("c", 4)
     # register ports: previous timestamp + 24-bit difference (16 + 8 bit limbs)
@@ -108,7 +111,10 @@ def build_cpu():
         ch.assert_zero((1 - is_real) * F[f])
 
     # ---------------- fetch
-    ch.send("program", [pc, rd, rs1, rs2] + imm + off + [tgt] + [F[f] for f in FLAGS], is_real)
+    ch.send("program", [pc, rd, rs1, rs2] + imm + off + [tgt, alu_op] + [F[f] for f in FLAGS], is_real)
+    # families that live in their own chips (shifts): the row only ships (op, a, b, c) over the alu bus;
+    # the receiving chip constrains a and range-checks its bytes
+    ch.send("alu", [alu_op] + a + b + c, F["is_alu"])
 
     # ---------------- register ports (memory bus, addresses 0..31)
     def port(addr, prev_val, val, prev_sh, same, prev_ts, ts, lo, hi, en):
@@ -292,6 +298,61 @@ def build_cpu():
     return ch
 
 
+def build_shift():
+    """SLL / SRL / SRA rows received from the cpu chip over the alu bus.  shift = 8*q + r: the bit shift by r
+    splits every byte with the multiplier m = 2^r, the byte shift by q moves whole bytes."""
+    ch = Chip("shift")
+    is_real = ch.col("is_real")
+    is_sll, is_srl, is_sra = ch.col("is_sll"), ch.col("is_srl"), ch.col("is_sra")
+    a, b, c = ch.cols("a", 4), ch.cols("b", 4), ch.cols("c", 4)
+    sh = ch.col("sh")
+    q = ch.cols("q", 3)          # byte shift 1..3 (0 = none set)
+    r = ch.cols("r", 8)          # one-hot bit shift 0..7
+    lo, hi, t = ch.cols("lo", 4), ch.cols("hi", 4), ch.cols("t", 4)
+    sgn = ch.col("sgn")
+    ch.assert_bool(is_real)
+    for x in (is_sll, is_srl, is_sra):
+        ch.assert_bool(x)
+    ch.assert_eq(is_sll + is_srl + is_sra, is_real)
+    for x in q + r:
+        ch.assert_bool(x)
+    ch.assert_eq(esum(r), is_real)
+    qs = esum(q)
+    ch.assert_zero(qs * (qs - 1))
+    q0 = 1 - qs
+    qq = [q0] + q
+    ch.assert_eq(sh, 8 * (q[0] + 2 * q[1] + 3 * q[2]) + esum(k * r[k] for k in range(8)))
+    m = esum((1 << k) * r[k] for k in range(8))            # 2^r
+    mi = esum((1 << (8 - k)) * r[k] for k in range(8))     # 2^(8-r)
+    sel_r = is_srl + is_sra
+    ch.receive("alu", [ALU_SLL * is_sll + ALU_SRL * is_srl + ALU_SRA * is_sra] + a + b + c, is_real)
+    ch.send("byte", [B_AND, sh, c[0], 31], is_real)        # shift amount = low five bits of c
+    ch.send("byte", [B_RANGE, 0, lo[0], lo[1]], is_real)
+    ch.send("byte", [B_RANGE, 0, lo[2], lo[3]], is_real)
+    ch.send("byte", [B_RANGE, 0, hi[0], hi[1]], is_real)
+    ch.send("byte", [B_RANGE, 0, hi[2], hi[3]], is_real)
+    ch.send("byte", [B_MSB, sgn, b[3], 0], is_sra)
+    ch.assert_zero((is_sll + is_srl) * sgn)
+    for i in range(4):
+        # left: b_i * 2^r = lo_i + 256 hi_i, shifted byte t_i = lo_i + hi_(i-1)
+        ch.assert_zero(is_sll * (b[i] * m - lo[i] - 256 * hi[i]))
+        ch.assert_zero(is_sll * (t[i] - lo[i] - (hi[i - 1] if i else Expr.const(0))))
+        # right: b_i = hi_i * 2^r + lo_i with lo_i < 2^r, shifted byte t_i = hi_i + lo_(i+1) * 2^(8-r);
+        # above the top byte sit the sign bits: lo_4 = sgn * (2^r - 1)
+        ch.assert_zero(sel_r * (b[i] - hi[i] * m - lo[i]))
+        ch.send("byte", [B_LTU, 1, lo[i], m], sel_r)
+        # (lo_4 * 2^(8-r) = sgn * (2^r - 1) * 2^(8-r) = sgn * (256 - 2^(8-r)) since 2^r * 2^(8-r) = 256)
+        up = lo[i + 1] * mi if i < 3 else sgn * (256 - mi)
+        ch.assert_zero(sel_r * (t[i] - hi[i] - up))
+    fill = 255 * sgn
+    for i in range(4):
+        left = esum(qq[k] * t[i - k] for k in range(4) if i - k >= 0)
+        right = esum(qq[k] * (t[i + k] if i + k < 4 else fill) for k in range(4))
+        ch.assert_zero(is_sll * (a[i] - left))
+        ch.assert_zero(sel_r * (a[i] - right))
+    return ch
+
+
 def build_mem_image():
     ch = Chip("mem_image")
     addr, v, real = ch.prep("addr"), ch.preps("v", 4), ch.prep("is_real")
@@ -325,4 +386,4 @@ def build_mem_init():
 
 
 def build():
-    return Machine("rv32", [build_program(), build_byte(), build_cpu(), build_mem_image(), build_mem_init()], BUSES)
+    return Machine("rv32", [build_program(), build_byte(), build_cpu(), build_mem_image(), build_mem_init(), build_shift()], BUSES)
