@@ -6,7 +6,11 @@
  * pinned only as sp1-sdk ^4.2.1 at reference Cargo.toml:31, source absent).
  *   external layer: M4 = circ(2,3,1,1) on every 4-chunk, then add the column
  *                   sums (Poseidon2 paper, section 5.1)
- *   internal layer: y_i = diag_i * x_i + sum(x),  diag = [-2,1,2,4,...,2^13,2^15]
+ *   internal layer: y_i = diag_i * x_i + sum(x),
+ *                   diag = [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 1/2^8, 1/4, 1/8, 1/2^27, -1/2^8, -1/16, -1/2^27]
+ *                   (the small-integer / inverse-power-of-two diagonal published for BabyBear width 16 by
+ *                   Plonky3; on gfx950 every entry is a handful of shifts and adds because
+ *                   2^-k = -15 * 2^(27-k) mod p — the HIP path exploits that, this file just multiplies)
  * The stock round-constant table (RC_16_30_U32, 480 words) is not in the
  * container, so the constants are derived here:
  *   block_i  = SHA-256("dvt-amd/poseidon2-babybear-w16/rc" || LE32(i))
@@ -46,9 +50,11 @@ __attribute__((constructor)) static void init_constants(void) {
     for (int r = 0; r < N_EXT; r++)
         for (int j = 0; j < 16; j++) RC_EXT[r][j] = all[r * 16 + j];
     for (int r = 0; r < N_INT; r++) RC_INT[r] = all[N_EXT * 16 + r];
-    DIAG[0] = BB_P - 2;
-    for (int i = 1; i < 15; i++) DIAG[i] = 1u << (i - 1);
-    DIAG[15] = 1u << 15;
+    {
+        bb_t i2 = bb_inv(2), i4 = bb_inv(4), i8 = bb_inv(8), i16 = bb_inv(16), i256 = bb_inv(256), i27 = bb_inv(1u << 27);
+        bb_t d[16] = {BB_P - 2, 1, 2, i2, 3, 4, bb_neg(i2), BB_P - 3, BB_P - 4, i256, i4, i8, i27, bb_neg(i256), bb_neg(i16), bb_neg(i27)};
+        memcpy(DIAG, d, sizeof d);
+    }
     inited = 1;
 }
 

@@ -21,7 +21,8 @@ def py_constants():
         i += 1
     ext = [out[r * 16 : (r + 1) * 16] for r in range(8)]
     internal = out[128 : 128 + 13]
-    diag = [P - 2] + [1 << k for k in range(14)] + [1 << 15]
+    inv = lambda x: pow(x, P - 2, P)
+    diag = [P - 2, 1, 2, inv(2), 3, 4, P - inv(2), P - 3, P - 4, inv(256), inv(4), inv(8), inv(1 << 27), P - inv(256), P - inv(16), P - inv(1 << 27)]
     return ext, internal, diag
 
 
