@@ -180,6 +180,10 @@ def main():
     prof.pk_free(ppk)
     prof.close()
     lde_gbps = ks["lde_alg_bytes"] / (ks["lde_ms"] * 1e-3) / 1e9 if ks["lde_ms"] else 0.0
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_k1_traffic.json")))
+    except OSError:
+        pmc = {}
 
     out = {
         "metric": "SP1 prover cycles/sec + proofs/hour, finalization_prove at 1/2/4/8 MI355X",
@@ -215,7 +219,9 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": lde_gbps / HBM_PEAK_GBPS,
-            "traffic": None,
+            "traffic": pmc.get("k1_hbm_bytes_per_proof"),
+            "traffic_source": "profiles/r1_pmc_k1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this command, "
+                              "gfx950 FETCH_SIZE x2 correction applied where the guide prescribes it); bytes per proof, like alg_bytes_per_proof",
             "alg_bytes_per_proof": ks["lde_alg_bytes"],
             "ms_per_proof": ks["lde_ms"],
         },
