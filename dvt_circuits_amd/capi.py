@@ -94,6 +94,7 @@ def load():
     lib.dvt_rv32_prove_shard.argtypes = [vp, vp, vp, sz, u32p, C.POINTER(u8p), C.POINTER(sz)]
     lib.dvt_rv32_assemble.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(sz), sz, C.POINTER(u8p), C.POINTER(sz)]
     lib.dvt_rv32_debug_device_traces.argtypes = [vp, vp, vp, sz, C.POINTER(u32p), C.POINTER(sz)]
+    lib.dvt_stdin_from_json.argtypes = [C.c_char_p, C.c_char_p, sz, C.c_int, C.POINTER(u8p), C.POINTER(sz), C.POINTER(C.c_char_p)]
     _lib = lib
     return lib
 
@@ -129,6 +130,20 @@ def execute(elf: bytes, stdin=(), max_cycles=0):
     if pv:
         lib.dvt_free(C.cast(pv, C.c_void_p))
     return rc, dict(cycles=rep.cycles, exit_code=rep.exit_code, halted=bool(rep.halted), unprovable=bool(rep.unprovable)), out, _take_str(lib, err)
+
+
+def stdin_from_json(circuit_type: str, json_bytes: bytes, auth_commitment=False) -> bytes:
+    """The one SP1Stdin buffer the reference's host writes for `circuit_type` (src/main.rs:448-459:
+    typed serde_json parse -> serde_cbor -> stdin.write(&Vec<u8>)).  Raises DvtError(DVT_ERR_INPUT) where the
+    reference's typed parse fails ("Failed to read input")."""
+    lib = load()
+    out, n, err = u8p(), C.c_size_t(), C.c_char_p()
+    rc = lib.dvt_stdin_from_json(circuit_type.encode(), json_bytes, len(json_bytes), int(bool(auth_commitment)), C.byref(out), C.byref(n), C.byref(err))
+    if rc:
+        raise DvtError(rc, _take_str(lib, err))
+    b = C.string_at(out, n.value)
+    lib.dvt_free(C.cast(out, C.c_void_p))
+    return b
 
 
 def verify(vk: bytes, proof: bytes, fri_queries=100, pow_bits=16):

@@ -180,6 +180,14 @@ int dvt_rv32_debug_device_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *job, 
  * `verify` sub-command).  Host-only. */
 int dvt_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, size_t proof_len, uint32_t fri_queries,
                uint32_t pow_bits, int32_t *exit_code, uint8_t **public_values, size_t *pv_len, char **reason);
+/* Host side of the reference's prove()/execute() above the prover call: the typed JSON input of
+ * `--type` (bad-share | finalization | bad-partial-key | bad-encrypted-share; crates/dkg/src/types.rs:26-203)
+ * -> serde_cbor::to_vec(data) (src/main.rs:435,459) -> the one SP1Stdin buffer (`stdin.write(&bin)`,
+ * :437,:460: u64-LE length + CBOR bytes).  auth_commitment != 0 adds the fields of the reference's
+ * cargo feature of that name.  Host-only; *out via dvt_free. */
+int dvt_stdin_from_json(const char *type, const char *json, size_t json_len, int auth_commitment, uint8_t **out,
+                        size_t *out_len, char **err_text);
+
 /* test hook, host-only: the traces (canonical, column-major) the prover would commit for shard
  * `shard` (0-based position) of this run cut at 2^log_shard cycles (0 = default 21).  Layout of *blob
  * (u32 words): n_chips present, then per chip {chip_id, log_n, main_width, prep_width}, then n_pub,
