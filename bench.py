@@ -180,6 +180,9 @@ def main():
     prof.pk_free(ppk)
     prof.close()
     lde_gbps = ks["lde_alg_bytes"] / (ks["lde_ms"] * 1e-3) / 1e9 if ks["lde_ms"] else 0.0
+    # compulsory streams of the whole shard, each counted once
+    shard_alg = 36 * ks["cells_main"] + 36 * ks["cells_perm"] + 28 * ks["cells_quotient"] + 24 * ks["cells_prep"]
+    step_s = dt / args.steps / max(len(mine), 1)
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_k1_traffic.json")))
     except OSError:
@@ -231,6 +234,13 @@ def main():
             "gperm_per_s": ks["merkle_perms"] / (ks["merkle_ms"] * 1e-3) / 1e9 if ks["merkle_ms"] else 0.0,
         },
         "stage_ms": stage,
+        "whole_shard": {
+            "alg_bytes": shard_alg,
+            "formula": "36 M + 36 P + 28 Q + 24 Pre (field elements of the main / permutation / quotient / preprocessed traces)",
+            "cells": {k: ks["cells_" + k] for k in ("main", "perm", "quotient", "prep")},
+            "achieved_GBps": shard_alg / step_s / 1e9,
+            "frac_of_hbm_peak": shard_alg / step_s / 1e9 / HBM_PEAK_GBPS,
+        },
     }
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:

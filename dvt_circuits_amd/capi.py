@@ -390,9 +390,10 @@ class Prover:
     def kernel_stats(self):
         """K1 / K2+K3 family totals of the last prove on a profile handle (HIP events on the prover stream)"""
         self.lib.dvt_last_kernel_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
-        out = (C.c_double * 5)()
+        out = (C.c_double * 9)()
         self.check(self.lib.dvt_last_kernel_stats(self.h, out))
-        return dict(lde_ms=out[0], lde_alg_bytes=out[1], lde_calls=int(out[2]), merkle_ms=out[3], merkle_perms=out[4])
+        return dict(lde_ms=out[0], lde_alg_bytes=out[1], lde_calls=int(out[2]), merkle_ms=out[3], merkle_perms=out[4],
+                    cells_main=out[5], cells_perm=out[6], cells_quotient=out[7], cells_prep=out[8])
 
     def stage_ms(self):
         out = (C.c_float * 6)()

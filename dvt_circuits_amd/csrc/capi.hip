@@ -11,6 +11,7 @@
 #include <string>
 
 #include "engine.h"
+#include "poseidon2_f64.cuh"
 #include "rv32.h"
 
 using namespace dvt;
@@ -353,10 +354,11 @@ int dvt_machine_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, s
     return DVT_OK;
 }
 
-int dvt_last_kernel_stats(dvt_prover *p, double out[5]) {
+int dvt_last_kernel_stats(dvt_prover *p, double out[9]) {
     if (!p || !out) return DVT_ERR_INPUT;
     const StageTimes &t = p->eng.times;
     out[0] = t.lde_ms; out[1] = t.lde_alg_bytes; out[2] = t.lde_calls; out[3] = t.merkle_ms; out[4] = t.merkle_perms;
+    out[5] = t.cells_m; out[6] = t.cells_p; out[7] = t.cells_q; out[8] = t.cells_pre;
     return DVT_OK;
 }
 
@@ -422,6 +424,10 @@ struct ShardJob {
     uint32_t *d_aux[rv32::N_CHIPS] = {};  // main traces except cpu
     std::vector<Fp> pubs;
     MainCache cache;  // phase-1 LDEs + tree of the main traces, consumed by phase 2
+    // K0 output of this shard kept from phase 1 to phase 2 (with the cache, while HBM allows); otherwise the
+    // job's working buffers are used and phase 2 runs K0 again
+    uint32_t *d_cpu = nullptr, *d_byte = nullptr, *d_prog = nullptr;
+    bool traces_valid = false;
 };
 // one prepared execution: executor output cut into shards, resident in HBM, ready for K0..K9
 struct dvt_job {
@@ -436,6 +442,7 @@ static void job_release(dvt_job *j) {
     for (auto &s : j->shards) {
         if (s.d_recs) (void)hipFree(s.d_recs);
         for (auto &d : s.d_aux) if (d) (void)hipFree(d);
+        for (uint32_t *d : {s.d_cpu, s.d_byte, s.d_prog}) if (d) (void)hipFree(d);
         s.cache.release();
     }
     if (j->d_cpu) (void)hipFree(j->d_cpu);
@@ -492,21 +499,25 @@ static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_buf
     return DVT_OK;
 }
 
-// K0 of shard i into the job's working buffers; fills the chip trace list of that shard
-static int shard_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *j, size_t i, std::vector<ChipTrace> *traces) {
+// K0 of shard i (into the shard's own buffers when it has them, else the job's working buffers); fills the chip
+// trace list of that shard.  `reuse`: phase 2 takes the traces phase 1 left behind instead of generating them again.
+static int shard_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *j, size_t i, std::vector<ChipTrace> *traces, bool reuse) {
     hipStream_t st = p->eng.stream;
     ShardJob &s = j->shards[i];
     const MachineDesc *m = machine_rv32();
-    bool ok = hipMemcpyAsync(j->d_byte, s.d_aux[RV32_CHIP_BYTE], j->byte_words * 4, hipMemcpyDeviceToDevice, st) == hipSuccess &&
-              hipMemcpyAsync(j->d_prog, s.d_aux[RV32_CHIP_PROGRAM], j->prog_words * 4, hipMemcpyDeviceToDevice, st) == hipSuccess &&
-              rv32::launch_k0_cpu_rows(st, s.d_recs, s.n_recs, s.index, s.pv_end, pk->d_instrs, pk->d_prog_row, j->d_cpu, s.log_n[RV32_CHIP_CPU], j->d_byte,
-                                       j->d_prog) == hipSuccess &&
-              launch_to_internal(st, j->d_byte, j->byte_words) == hipSuccess && launch_to_internal(st, j->d_prog, j->prog_words) == hipSuccess;
-    if (!ok) return fail(p, DVT_ERR_DEVICE, "trace generation (K0) failed: %s", hipGetErrorString(hipGetLastError()));
+    uint32_t *cpu = s.d_cpu ? s.d_cpu : j->d_cpu, *byte = s.d_cpu ? s.d_byte : j->d_byte, *prog = s.d_cpu ? s.d_prog : j->d_prog;
+    if (!(reuse && s.d_cpu && s.traces_valid)) {
+        bool ok = hipMemcpyAsync(byte, s.d_aux[RV32_CHIP_BYTE], j->byte_words * 4, hipMemcpyDeviceToDevice, st) == hipSuccess &&
+                  hipMemcpyAsync(prog, s.d_aux[RV32_CHIP_PROGRAM], j->prog_words * 4, hipMemcpyDeviceToDevice, st) == hipSuccess &&
+                  rv32::launch_k0_cpu_rows(st, s.d_recs, s.n_recs, s.index, s.pv_end, pk->d_instrs, pk->d_prog_row, cpu, s.log_n[RV32_CHIP_CPU], byte, prog) == hipSuccess &&
+                  launch_to_internal(st, byte, j->byte_words) == hipSuccess && launch_to_internal(st, prog, j->prog_words) == hipSuccess;
+        if (!ok) return fail(p, DVT_ERR_DEVICE, "trace generation (K0) failed: %s", hipGetErrorString(hipGetLastError()));
+        s.traces_valid = s.d_cpu != nullptr;
+    }
     traces->clear();
     for (int c = 0; c < m->n_chips; c++) {
         if (!s.present[c]) continue;
-        const uint32_t *ptr = c == RV32_CHIP_CPU ? j->d_cpu : c == RV32_CHIP_BYTE ? j->d_byte : c == RV32_CHIP_PROGRAM ? j->d_prog : s.d_aux[c];
+        const uint32_t *ptr = c == RV32_CHIP_CPU ? cpu : c == RV32_CHIP_BYTE ? byte : c == RV32_CHIP_PROGRAM ? prog : s.d_aux[c];
         traces->push_back({c, s.log_n[c], ptr});
     }
     return DVT_OK;
@@ -514,13 +525,22 @@ static int shard_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *j, size_t i, s
 
 static int shard_commit(dvt_prover *p, const dvt_pk *pk, dvt_job *j, size_t i, uint32_t header[HEADER_WORDS]) {
     std::vector<ChipTrace> traces;
-    int rc = shard_traces(p, pk, j, i, &traces);
-    if (rc) return rc;
-    Digest root;
-    // keep the phase-1 results in HBM while they fit (about 2 GB per 2^21-cycle shard); otherwise phase 2 recomputes
+    ShardJob &s = j->shards[i];
+    // keep the phase-1 results in HBM while they fit (about 3 GB per 2^21-cycle shard); otherwise phase 2 recomputes
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
-    MainCache *keep = (j->shards[i].cache.tree || free_b > ((size_t)24 << 30)) ? &j->shards[i].cache : nullptr;
+    MainCache *keep = (s.cache.tree || free_b > ((size_t)24 << 30)) ? &s.cache : nullptr;
+    if (keep && !s.d_cpu) {
+        bool ok = hipMalloc(&s.d_cpu, ((size_t)RV32_CPU_MAIN_W << s.log_n[RV32_CHIP_CPU]) * 4) == hipSuccess && hipMalloc(&s.d_byte, j->byte_words * 4) == hipSuccess &&
+                  hipMalloc(&s.d_prog, j->prog_words * 4) == hipSuccess;
+        if (!ok) {  // not fatal: fall back to the shared working buffers
+            (void)hipGetLastError();
+            for (uint32_t **d : {&s.d_cpu, &s.d_byte, &s.d_prog}) { if (*d) (void)hipFree(*d); *d = nullptr; }
+        }
+    }
+    int rc = shard_traces(p, pk, j, i, &traces, false);
+    if (rc) return rc;
+    Digest root;
     if (!p->eng.commit_main_root(pk->key, traces, &root, keep)) return fail(p, DVT_ERR_DEVICE, "%s", p->eng.err.c_str());
     for (int k = 0; k < 8; k++) header[k] = root.d[k].canonical();
     for (uint32_t k = 0; k < N_PUB; k++) header[8 + k] = j->shards[i].pubs[k].canonical();
@@ -529,12 +549,13 @@ static int shard_commit(dvt_prover *p, const dvt_pk *pk, dvt_job *j, size_t i, u
 
 static int shard_prove(dvt_prover *p, const dvt_pk *pk, dvt_job *j, size_t i, const PermChallenges &gc, std::vector<uint32_t> *words) {
     std::vector<ChipTrace> traces;
-    int rc = shard_traces(p, pk, j, i, &traces);
+    int rc = shard_traces(p, pk, j, i, &traces, j->shards[i].cache.valid);
     if (rc) return rc;
     ShardProof sp;
     bool ok = p->eng.prove_shard(pk->key, traces, j->shards[i].pubs, p->cfg, &sp, &gc, &j->shards[i].cache);
     (void)hipStreamSynchronize(p->eng.stream);
     j->shards[i].cache.valid = false;  // the buffers stay for the next commit of this shard (released with the job)
+    j->shards[i].traces_valid = false;
     if (!ok) return fail(p, DVT_ERR_DEVICE, "%s", p->eng.err.c_str());
     WordWriter w;
     write_shard_proof(w, sp);
@@ -870,7 +891,7 @@ int dvt_rv32_debug_device_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *j, si
     std::lock_guard<std::mutex> lk(p->mu);
     HIP_TRY(p, hipSetDevice(p->eng.device));
     std::vector<ChipTrace> traces;
-    int rc = shard_traces(p, pk, j, shard, &traces);
+    int rc = shard_traces(p, pk, j, shard, &traces, false);
     if (rc) return rc;
     HIP_TRY(p, hipStreamSynchronize(p->eng.stream));
     const MachineDesc *m = machine_rv32();
@@ -891,6 +912,30 @@ int dvt_rv32_debug_device_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *j, si
     memcpy(*blob, w.data(), w.size() * 4);
     *blob_words = w.size();
     return DVT_OK;
+}
+
+// test hook (host only): the FP64 formulation of Poseidon2 that the hashing kernels run, evaluated on the host
+// (IEEE doubles + fma, the same arithmetic) against the integer permutation on n pseudo-random and edge-case states,
+// through the same Montgomery conversions the kernels use.  Returns the number of differing words.
+uint64_t dvt_debug_p2_f64_selfcheck(uint32_t n, uint32_t seed) {
+    uint64_t bad = 0, x = 0x9e3779b97f4a7c15ull ^ seed;
+    for (uint32_t t = 0; t < n; t++) {
+        Fp a[16];
+        double b[16];
+        for (int i = 0; i < 16; i++) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            uint32_t v = (uint32_t)(x % P);
+            if (t < 4) v = t == 0 ? 0 : t == 1 ? P - 1 : t == 2 ? (P - 1) / 2 + (i & 1) : (i ? P - i : 1);
+            a[i] = Fp::from_canonical(v);
+            b[i] = p2f::from_mont(a[i].v);
+        }
+        for (int rep = 0; rep < 3; rep++) {  // chained: the second and third calls start from lazy (signed) outputs
+            p2_permute(a);
+            p2f::permute(b);
+            for (int i = 0; i < 16; i++) bad += (a[i].v != p2f::to_mont(b[i])) + (a[i].canonical() != p2f::to_canonical(b[i]));
+        }
+    }
+    return bad;
 }
 
 }  // extern "C"

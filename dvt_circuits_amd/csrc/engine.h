@@ -110,6 +110,9 @@ struct StageTimes {  // milliseconds, HIP events on the prover stream (profile m
     int lde_calls = 0;
     float merkle_ms = 0;       // K2 + K3 of the three trace commitments (leaf hashing + levels)
     double merkle_perms = 0;   // Poseidon2 permutations executed by them
+    // committed cells of the shard in BabyBear elements: main, permutation and quotient
+    // (both flattened over F_p^4), preprocessed
+    double cells_m = 0, cells_p = 0, cells_q = 0, cells_pre = 0;
 };
 
 class Engine {

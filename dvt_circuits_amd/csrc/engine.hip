@@ -357,6 +357,11 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
         times.lde_ms = phase1.lde_ms; times.lde_alg_bytes = phase1.lde_alg_bytes; times.lde_calls = phase1.lde_calls;
         times.merkle_ms = phase1.merkle_ms; times.merkle_perms = phase1.merkle_perms;
     }
+    for (auto &t : traces) {
+        const ChipDesc &d = m->chips[t.chip_id];
+        const double n = (double)((size_t)1 << t.log_n);
+        times.cells_m += d.main_w * n; times.cells_p += 4.0 * d.perm_ext_w * n; times.cells_q += 8.0 * n; times.cells_pre += d.prep_w * n;
+    }
     EventTimer tm(stream, profile), tm_total(stream, profile);
     // per-family timing (profile mode only: the extra event synchronisations serialise the stream)
     auto lde = [&](uint32_t *in, uint32_t *scratch, uint32_t *outp, uint32_t width, uint32_t log_n, uint32_t mode) -> hipError_t {

@@ -4,6 +4,7 @@
 // the pair (i, i + M/2), so both operands of every fold are coalesced streams and
 // a layer's Merkle leaf i is the pair itself.
 #include "kernels.h"
+#include "poseidon2_f64.cuh"
 
 namespace dvt {
 
@@ -215,15 +216,15 @@ __global__ void __launch_bounds__(256) fri_leaves_kernel(const Fp4 *v, size_t ha
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
     Fp4 lo = load_ext(v + i), hi = load_ext(v + i + half);
-    Fp s[16];
+    double s[16];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { s[k] = lo.c[k]; s[4 + k] = hi.c[k]; }
+    for (int k = 0; k < 4; k++) { s[k] = p2f::from_mont(lo.c[k].v); s[4 + k] = p2f::from_mont(hi.c[k].v); }
 #pragma unroll
-    for (int k = 8; k < 16; k++) s[k] = Fp::zero();
-    p2_permute(s);
+    for (int k = 8; k < 16; k++) s[k] = 0.0;
+    p2f::permute(s);
     uint4 *o = reinterpret_cast<uint4 *>(out + i * 8);
-    o[0] = make_uint4(s[0].v, s[1].v, s[2].v, s[3].v);
-    o[1] = make_uint4(s[4].v, s[5].v, s[6].v, s[7].v);
+    o[0] = make_uint4(p2f::to_mont(s[0]), p2f::to_mont(s[1]), p2f::to_mont(s[2]), p2f::to_mont(s[3]));
+    o[1] = make_uint4(p2f::to_mont(s[4]), p2f::to_mont(s[5]), p2f::to_mont(s[6]), p2f::to_mont(s[7]));
 }
 hipError_t launch_fri_leaves(hipStream_t st, const Fp4 *d_v, uint32_t log_m, uint32_t *d_digests) {
     size_t half = (size_t)1 << (log_m - 1);
@@ -281,15 +282,14 @@ __global__ void __launch_bounds__(256) pow_grind_kernel(GrindArgs a, uint32_t *f
     if (t >= a.count) return;
     uint32_t w = a.base + t;
     if (w >= P) return;
-    Fp s[16];
+    double s[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) s[k] = Fp::raw(a.state[k]);
-    Fp wm = Fp::from_canonical(w);
+    for (int k = 0; k < 16; k++) s[k] = p2f::from_mont(a.state[k]);
 #pragma unroll
     for (int k = 0; k < 8; k++)
-        if ((uint32_t)k == a.pos) s[k] = wm;
-    p2_permute(s);
-    if ((s[7].canonical() & a.mask) == 0) atomicMin(found, w);
+        if ((uint32_t)k == a.pos) s[k] = p2f::from_canonical(w);
+    p2f::permute(s);
+    if ((p2f::to_canonical(s[7]) & a.mask) == 0) atomicMin(found, w);
 }
 hipError_t launch_pow_grind(hipStream_t st, const uint32_t state[16], uint32_t pos, uint32_t bits, uint32_t base, uint32_t count,
                             uint32_t *d_found) {

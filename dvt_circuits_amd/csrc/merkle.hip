@@ -12,41 +12,55 @@
 // so row r of a tall matrix and row r mod L of a shorter one share a path (the
 // relation natural-order FRI folding needs) and both child reads are coalesced.
 //
-// ALU-bound (about 141 S-boxes = 564 Montgomery products per permutation, one
-// permutation per 8 input words), not HBM-bound: see DESIGN.md.
+// ALU-bound (141 S-boxes = 564 modular products per permutation, one permutation per 8 input words), not
+// HBM-bound.  The permutation runs on the FP64 pipe (poseidon2_f64.cuh: exact integers in doubles, 6 full-rate
+// operations per product instead of 3 quarter-rate integer multiplies); states stay in doubles between the
+// permutations of one sponge and are converted from / to the Montgomery words of HBM at the edges.
 #include "kernels.h"
+#include "poseidon2_f64.cuh"
 
 namespace dvt {
 
-__device__ __forceinline__ void hash_row(const uint32_t *const *cols, uint32_t ncols, size_t row, Fp s[16]) {
+// sponge over the row `row` of the concatenated matrices; leaves the state reduced (digest = s[0..8))
+__device__ __forceinline__ void hash_row(const uint32_t *const *cols, uint32_t ncols, size_t row, double s[16]) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = Fp::zero();
+    for (int i = 0; i < 16; i++) s[i] = 0.0;
     uint32_t g = 0;
     for (; g + 8 <= ncols; g += 8) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) s[k] = Fp::raw(cols[g + k][row]);
-        p2_permute(s);
+        for (int k = 0; k < 8; k++) s[k] = p2f::from_mont(cols[g + k][row]);
+        p2f::permute(s);
     }
     const uint32_t rem = ncols - g;
     if (rem) {
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            if ((uint32_t)k < rem) s[k] = Fp::raw(cols[g + k][row]);
-        p2_permute(s);
+            if ((uint32_t)k < rem) s[k] = p2f::from_mont(cols[g + k][row]);
+        p2f::permute(s);
     }
 }
 
-__device__ __forceinline__ void store_digest(uint32_t *out, size_t node, const Fp s[16]) {
+__device__ __forceinline__ void store_digest(uint32_t *out, size_t node, const double s[16]) {
     uint4 *o = reinterpret_cast<uint4 *>(out + node * 8);
-    o[0] = make_uint4(s[0].v, s[1].v, s[2].v, s[3].v);
-    o[1] = make_uint4(s[4].v, s[5].v, s[6].v, s[7].v);
+    o[0] = make_uint4(p2f::to_mont(s[0]), p2f::to_mont(s[1]), p2f::to_mont(s[2]), p2f::to_mont(s[3]));
+    o[1] = make_uint4(p2f::to_mont(s[4]), p2f::to_mont(s[5]), p2f::to_mont(s[6]), p2f::to_mont(s[7]));
+}
+
+// children i and i + len of a layer of 2 len digests -> the 16-word compression input
+__device__ __forceinline__ void load_children(const uint32_t *prev, size_t i, size_t len, double s[16]) {
+    const uint4 *pl = reinterpret_cast<const uint4 *>(prev + i * 8);
+    const uint4 *pr = reinterpret_cast<const uint4 *>(prev + (i + len) * 8);
+    uint4 a = pl[0], b = pl[1], c = pr[0], d = pr[1];
+    const uint32_t w[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int k = 0; k < 16; k++) s[k] = p2f::from_mont(w[k]);
 }
 
 __global__ void __launch_bounds__(256) merkle_leaves_kernel(const uint32_t *const *cols, uint32_t ncols, size_t height,
                                                            uint32_t *out) {
     size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= height) return;
-    Fp s[16];
+    double s[16];
     hash_row(cols, ncols, row, s);
     store_digest(out, row, s);
 }
@@ -56,19 +70,15 @@ __global__ void __launch_bounds__(256) merkle_level_kernel(const uint32_t *prev,
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= len) return;
     // natural-order pairing: children i and i + len (two coalesced 32-B-per-lane streams)
-    const uint4 *pl = reinterpret_cast<const uint4 *>(prev + i * 8);
-    const uint4 *pr = reinterpret_cast<const uint4 *>(prev + (i + len) * 8);
-    uint4 a = pl[0], b = pl[1], c = pr[0], d = pr[1];
-    Fp s[16] = {Fp::raw(a.x), Fp::raw(a.y), Fp::raw(a.z), Fp::raw(a.w), Fp::raw(b.x), Fp::raw(b.y),
-                Fp::raw(b.z), Fp::raw(b.w), Fp::raw(c.x), Fp::raw(c.y), Fp::raw(c.z), Fp::raw(c.w),
-                Fp::raw(d.x), Fp::raw(d.y), Fp::raw(d.z), Fp::raw(d.w)};
-    p2_permute(s);
+    double s[16];
+    load_children(prev, i, len, s);
+    p2f::permute(s);
     if (ncols) {
-        Fp h[16];
+        double h[16];
         hash_row(cols, ncols, i, h);
 #pragma unroll
         for (int k = 0; k < 8; k++) s[8 + k] = h[k];
-        p2_permute(s);
+        p2f::permute(s);
     }
     store_digest(out, i, s);
 }
@@ -83,19 +93,15 @@ __global__ void __launch_bounds__(1024) merkle_top_kernel(uint32_t *layer, uint3
         const size_t len = (size_t)1 << lh;
         uint32_t *cur = prev + ((size_t)16 << lh);
         for (size_t i = threadIdx.x; i < len; i += blockDim.x) {
-            const uint4 *pl = reinterpret_cast<const uint4 *>(prev + i * 8);
-            const uint4 *pr = reinterpret_cast<const uint4 *>(prev + (i + len) * 8);
-            uint4 a = pl[0], b = pl[1], c = pr[0], d = pr[1];
-            Fp s[16] = {Fp::raw(a.x), Fp::raw(a.y), Fp::raw(a.z), Fp::raw(a.w), Fp::raw(b.x), Fp::raw(b.y),
-                        Fp::raw(b.z), Fp::raw(b.w), Fp::raw(c.x), Fp::raw(c.y), Fp::raw(c.z), Fp::raw(c.w),
-                        Fp::raw(d.x), Fp::raw(d.y), Fp::raw(d.z), Fp::raw(d.w)};
-            p2_permute(s);
+            double s[16];
+            load_children(prev, i, len, s);
+            p2f::permute(s);
             if (inj.ncols[lh]) {
-                Fp h[16];
+                double h[16];
                 hash_row(inj.cols[lh], inj.ncols[lh], i, h);
 #pragma unroll
                 for (int k = 0; k < 8; k++) s[8 + k] = h[k];
-                p2_permute(s);
+                p2f::permute(s);
             }
             store_digest(cur, i, s);
         }
@@ -116,12 +122,12 @@ hipError_t launch_merkle_top(hipStream_t st, uint32_t *d_layer, uint32_t log_sta
 __global__ void poseidon2_permute_kernel(uint32_t *states, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fp s[16];
+    double s[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) s[k] = Fp::raw(states[i * 16 + k]);
-    p2_permute(s);
+    for (int k = 0; k < 16; k++) s[k] = p2f::from_mont(states[i * 16 + k]);
+    p2f::permute(s);
 #pragma unroll
-    for (int k = 0; k < 16; k++) states[i * 16 + k] = s[k].v;
+    for (int k = 0; k < 16; k++) states[i * 16 + k] = p2f::to_mont(s[k]);
 }
 
 hipError_t launch_merkle_leaves(hipStream_t st, const uint32_t *const *d_cols, uint32_t ncols, uint32_t log_height,

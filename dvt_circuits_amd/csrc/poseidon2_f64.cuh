@@ -1,0 +1,144 @@
+// Poseidon2 (the permutation of poseidon2.cuh, bit for bit) for the gfx950 hashing kernels, computed on the
+// FP64 pipe instead of the integer multiplier.
+//
+// Why: v_mul_lo/hi_u32 issue at quarter rate on gfx950 and a Montgomery product needs three of them, which
+// bounds the integer permutation at about 4.5 Gperm/s per GPU (measured, tools/microbench).  v_fma_f64 issues at
+// full rate, a modular product costs six FP64 operations and additions need no reduction at all, which measures
+// 6.5 Gperm/s for the same function.  (No MFMA: nothing here is a contraction.)
+//
+// How: a field element is an INTEGER carried in a double, congruent mod p to the value, of bounded magnitude
+// ("lazy").  Integers below 2^53 are exact in a double, an FMA rounds once, so every step below is exact integer
+// arithmetic as long as the stated bounds hold; they are stated at each function and the whole permutation is
+// compared with the integer one over 2^24 states by tools/microbench/p2_f64_bench.hip and by the GPU parity
+// tests (Merkle roots and proof bytes against the CPU oracle).
+//   mm(a, b):  h = RN(a b), l = a b - h (exact, one FMA), q = round(h / p), r = (h - q p) + l.
+//              Needs |a b| < 2^82 (q < 2^51 for the rounding trick).  |r| <= p/2 + |h| 2^-52 + |l| < 0.51 p
+//              for |a b| < 2^76.
+// HBM keeps Montgomery words (bb.cuh); from_mont / to_mont convert at the edges (one product each).
+#pragma once
+#include <math.h>
+#include "bb.cuh"
+#include "poseidon2_rc.inc"
+
+namespace dvt {
+namespace p2f {
+
+// (host-callable as well: IEEE doubles and fma() behave the same there, which is how the CPU test suite checks
+// this file against the integer permutation without a GPU)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DVT_F64_TABLE static __constant__ const
+#else
+#define DVT_F64_TABLE static const
+#endif
+#define DVT_DEV DVT_HD
+DVT_F64_TABLE double RC_EXT[128] = DVT_P2_RC_EXT_F64_INIT;
+DVT_F64_TABLE double RC_INT[13] = DVT_P2_RC_INT_F64_INIT;
+
+constexpr double PD = 2013265921.0;
+constexpr double PINV = 1.0 / 2013265921.0;
+constexpr double MAGIC = 6755399441055744.0;  // 1.5 * 2^52: (x + MAGIC) - MAGIC = x rounded to an integer, |x| < 2^51
+constexpr double MONT_R = 268435454.0;        // 2^32 mod p
+constexpr double MONT_RINV = 943718400.0;     // 2^-32 mod p
+
+DVT_DEV double rnd(double x) { return (x + MAGIC) - MAGIC; }
+DVT_DEV double mm(double a, double b) {
+    double h = a * b;
+    double l = fma(a, b, -h);
+    double q = rnd(h * PINV);
+    return fma(-q, PD, h) + l;
+}
+// |a| < 2^51  ->  the representative in [-p/2, p/2] (+- a rounding slack far below 1 for |a| < 2^48)
+DVT_DEV double red(double a) { return fma(-rnd(a * PINV), PD, a); }
+
+DVT_DEV double from_mont(uint32_t m) { return mm((double)m, MONT_RINV); }
+DVT_DEV double from_canonical(uint32_t c) { return (double)c; }
+// r in (-p, p) -> canonical word
+DVT_DEV uint32_t fix(double r) { return (uint32_t)(r < 0.0 ? r + PD : r); }
+DVT_DEV uint32_t to_mont(double x) { return fix(mm(x, MONT_R)); }      // |x| < 2^48
+DVT_DEV uint32_t to_canonical(double x) { return fix(red(x)); }       // |x| < 2^48
+
+DVT_DEV double sbox(double x) {  // |x| < 2^38
+    double x2 = mm(x, x), x3 = mm(x2, x), x4 = mm(x2, x2);
+    return mm(x3, x4);
+}
+
+// max |s| = B  ->  <= 35 B
+DVT_DEV void external_layer(double s[16]) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        double x0 = s[4 * c], x1 = s[4 * c + 1], x2 = s[4 * c + 2], x3 = s[4 * c + 3];
+        double t = (x0 + x1) + (x2 + x3);
+        s[4 * c + 0] = fma(2.0, x1, t + x0);
+        s[4 * c + 1] = fma(2.0, x2, t + x1);
+        s[4 * c + 2] = fma(2.0, x3, t + x2);
+        s[4 * c + 3] = fma(2.0, x0, t + x3);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        double sum = (s[k] + s[4 + k]) + (s[8 + k] + s[12 + k]);
+#pragma unroll
+        for (int c = 0; c < 4; c++) s[4 * c + k] += sum;
+    }
+}
+
+// y_i = sum + d_i x_i, d = [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 2^-8, 1/4, 1/8, 2^-27, -2^-8, -1/16, -2^-27] (poseidon2.cuh);
+// as centred residues 2^-27 = -15, 2^-k = -15 * 2^(27-k), 1/2 = -(p-1)/2.  max |s| = B (< 2^48) -> <= 31 B.
+template <bool REDUCE>
+DVT_DEV void internal_layer(double s[16]) {
+    if (REDUCE) {
+#pragma unroll
+        for (int i = 1; i < 16; i++) s[i] = red(s[i]);
+    }
+    double sum = s[0];
+#pragma unroll
+    for (int i = 1; i < 16; i++) sum += s[i];
+    s[0] = fma(-2.0, s[0], sum);
+    s[1] = sum + s[1];
+    s[2] = fma(2.0, s[2], sum);
+    s[3] = sum + mm(s[3], -1006632960.0);
+    s[4] = fma(3.0, s[4], sum);
+    s[5] = fma(4.0, s[5], sum);
+    s[6] = sum + mm(s[6], 1006632960.0);
+    s[7] = fma(-3.0, s[7], sum);
+    s[8] = fma(-4.0, s[8], sum);
+    s[9] = sum + mm(s[9], -7864320.0);
+    s[10] = sum + mm(s[10], -503316480.0);
+    s[11] = sum + mm(s[11], -251658240.0);
+    s[12] = fma(-15.0, s[12], sum);
+    s[13] = sum + mm(s[13], 7864320.0);
+    s[14] = sum + mm(s[14], 125829120.0);
+    s[15] = fma(15.0, s[15], sum);
+}
+
+// in: |s_i| < 2^32 (canonical words, from_mont results or a previous output); out: |s_i| < 0.51 p.
+// Magnitudes: after an S-box layer every entry is below 0.51 p (2^30.03), the external layer multiplies the bound
+// by 35 (2^35.2, the S-box input bound with a round constant added); in the internal rounds s[0] is reduced before
+// each S-box and the other entries every third round: 2^35.2 -> x31 -> 2^40.2 -> 2^45.1 -> reduce, and from a
+// reduced state 2^30 -> 2^35 -> 2^40 -> 2^45 (< 2^48 as the sums and the products with |d| < 2^30 need).
+DVT_DEV void permute(double s[16]) {
+    external_layer(s);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = sbox(s[i] + RC_EXT[16 * r + i]);
+        external_layer(s);
+    }
+#pragma unroll
+    for (int r = 0; r < 13; r++) {
+        s[0] = sbox(red(s[0]) + RC_INT[r]);
+        if (r == 2 || r == 5 || r == 8 || r == 11) internal_layer<true>(s); else internal_layer<false>(s);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = red(s[i]);
+#pragma unroll
+    for (int r = 4; r < 8; r++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = sbox(s[i] + RC_EXT[16 * r + i]);
+        external_layer(s);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = red(s[i]);
+}
+
+}  // namespace p2f
+}  // namespace dvt

@@ -118,8 +118,10 @@ int dvt_last_stage_ms(dvt_prover *p, float out[6]);
 /* kernel-family totals of the last prove on this handle (needs "profile":1), measured with HIP
  * events on the prover stream: out[0] = K1 LDE milliseconds, out[1] = K1 algorithmic bytes
  * (12 B per input element: read N, write 2N words per column), out[2] = K1 calls,
- * out[3] = K2+K3 (trace commitments) milliseconds, out[4] = Poseidon2 permutations they ran */
-int dvt_last_kernel_stats(dvt_prover *p, double out[5]);
+ * out[3] = K2+K3 (trace commitments) milliseconds, out[4] = Poseidon2 permutations they ran,
+ * out[5..8] = committed cells of the shard in field elements: main, permutation, quotient (both
+ * flattened over F_p^4), preprocessed -- the M, P, Q, Pre of SURVEY.md section 8d */
+int dvt_last_kernel_stats(dvt_prover *p, double out[9]);
 
 /* ------------------------------------------------- the reference's boundary
  * These five calls are what the reference's FFI for this path binds
@@ -180,6 +182,10 @@ int dvt_rv32_debug_device_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *job, 
  * `verify` sub-command).  Host-only. */
 int dvt_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, size_t proof_len, uint32_t fri_queries,
                uint32_t pow_bits, int32_t *exit_code, uint8_t **public_values, size_t *pv_len, char **reason);
+/* test hook, host only: FP64 formulation of Poseidon2 (csrc/poseidon2_f64.cuh, what the hashing kernels run)
+ * against the integer permutation on n states; returns the number of differing words (0 = identical) */
+uint64_t dvt_debug_p2_f64_selfcheck(uint32_t n, uint32_t seed);
+
 /* Host side of the reference's prove()/execute() above the prover call: the typed JSON input of
  * `--type` (bad-share | finalization | bad-partial-key | bad-encrypted-share; crates/dkg/src/types.rs:26-203)
  * -> serde_cbor::to_vec(data) (src/main.rs:435,459) -> the one SP1Stdin buffer (`stdin.write(&bin)`,

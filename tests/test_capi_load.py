@@ -30,3 +30,16 @@ def test_create_without_gpu_fails_loudly(prover_lib):
     rc = prover_lib.dvt_prover_create(None, ctypes.byref(h))
     assert rc == 3 and not h.value
     assert b"no CPU fallback" in prover_lib.dvt_last_error(None)
+
+
+def test_fp64_poseidon2_matches_integer_permutation_on_host():
+    """the hashing kernels evaluate Poseidon2 with exact integers carried in doubles (csrc/poseidon2_f64.cuh);
+    the same code on the host (IEEE doubles, fma) must reproduce the integer permutation word for word"""
+    import ctypes as C
+
+    from dvt_circuits_amd import capi
+
+    lib = capi.load()
+    lib.dvt_debug_p2_f64_selfcheck.restype = C.c_uint64
+    lib.dvt_debug_p2_f64_selfcheck.argtypes = [C.c_uint32, C.c_uint32]
+    assert lib.dvt_debug_p2_f64_selfcheck(20000, 1) == 0
