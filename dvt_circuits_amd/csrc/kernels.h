@@ -16,9 +16,14 @@ namespace dvt {
 // Device-resident two-level power tables (built once per prover handle).
 //   Omega = primitive 2^24-th root:  Omega^e = tw_hi[e >> 12] * tw_lo[e & 4095]
 //   g = 31 (coset shift):            g^k     = sh_hi[k >> 12] * sh_lo[k & 4095], k < 2^23
+//   lde_tw:    for every transform size 2^l, 1 <= l <= 13, the 2^(l-1) twiddles w_{2^l}^e at offset 2^(l-1) - 1
+//   lde_scale: for every (shift_mode, log_n) the per-position coefficient scaling of lde_block (4096 words each,
+//              at ((mode * LDE_MAX_LOG + log_n) << 12)): see ntt.hip
+constexpr uint32_t LDE_MAX_LOG = 23;
 struct NttTables {
     uint32_t *base = nullptr;
     const uint32_t *tw_hi = nullptr, *tw_lo = nullptr, *sh_hi = nullptr, *sh_lo = nullptr;
+    const uint32_t *lde_tw = nullptr, *lde_scale = nullptr;
 };
 hipError_t ntt_tables_create(NttTables *t);
 void ntt_tables_destroy(NttTables *t);

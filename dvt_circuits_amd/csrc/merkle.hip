@@ -25,17 +25,24 @@ namespace dvt {
 __device__ __forceinline__ void hash_row(const uint32_t *const *cols, uint32_t ncols, size_t row, double s[16]) {
 #pragma unroll
     for (int i = 0; i < 16; i++) s[i] = 0.0;
+    // the words of the next 8 columns are requested before the current block is permuted (a permutation is ~6 k
+    // FP64 operations, far longer than an HBM round trip)
+    uint32_t w[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = (uint32_t)k < ncols ? cols[k][row] : 0u;
     uint32_t g = 0;
     for (; g + 8 <= ncols; g += 8) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) s[k] = p2f::from_mont(cols[g + k][row]);
+        for (int k = 0; k < 8; k++) s[k] = p2f::from_mont(w[k]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) w[k] = g + 8 + k < ncols ? cols[g + 8 + k][row] : 0u;
         p2f::permute(s);
     }
     const uint32_t rem = ncols - g;
     if (rem) {
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            if ((uint32_t)k < rem) s[k] = p2f::from_mont(cols[g + k][row]);
+            if ((uint32_t)k < rem) s[k] = p2f::from_mont(w[k]);
         p2f::permute(s);
     }
 }
