@@ -805,7 +805,7 @@ int dvt_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, size_t pr
             if (pubv[5] != (i ? sps[i - 1].public_values[6].canonical() : 0u)) return reject(DVT_ERR_REJECTED, "public-value counters do not chain");
             if (pubv[6] < pubv[5]) return reject(DVT_ERR_REJECTED, "public-value counter decreases");
             if (last && (pvl % 4 || pubv[6] != pvl / 4)) return reject(DVT_ERR_REJECTED, "number of committed public-value words does not match");
-            // chip set: program, byte, cpu, mem_image always; mem_init in the last shard only; shift when the shard shifts
+            // chip set: program, byte, cpu, mem_image always; mem_init in the last shard only; shift / muldiv when the shard uses them
             bool have[rv32::N_CHIPS] = {};
             for (auto &c : sp.chips) have[c.chip_id] = true;
             for (int c : {RV32_CHIP_PROGRAM, RV32_CHIP_BYTE, RV32_CHIP_CPU, RV32_CHIP_MEM_IMAGE})

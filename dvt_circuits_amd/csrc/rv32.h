@@ -36,8 +36,9 @@ constexpr uint32_t B_AND = 1, B_OR = 2, B_XOR = 3, B_LTU = 4, B_MSB = 5, B_RANGE
 constexpr int N_BYTE_OPS = 7;  // multiplicity columns of the byte chip, in this order: and or xor ltu msb range u16
 constexpr uint32_t ADDR_LIMIT = 1u << 30;
 constexpr uint32_t SYS_COMMIT = 0x10;
-constexpr uint32_t ALU_SLL = 1, ALU_SRL = 2, ALU_SRA = 3;  // alu-bus opcodes (chips outside the cpu chip)
-constexpr int N_CHIPS = 6;                                 // program, byte, cpu, mem_image, mem_init, shift
+constexpr uint32_t ALU_SLL = 1, ALU_SRL = 2, ALU_SRA = 3;  // alu-bus opcodes (chips outside the cpu chip): shift chip
+constexpr uint32_t ALU_MULH = 4, ALU_MULHSU = 5, ALU_DIV = 6, ALU_DIVU = 7, ALU_REM = 8, ALU_REMU = 9;  // muldiv chip
+constexpr int N_CHIPS = 7;  // program, byte, cpu, mem_image, mem_init, shift, muldiv
 constexpr uint32_t N_PUBLIC = 7;  // start_pc, next_pc, exit_code, shard, is_last, pv_start, pv_end
 
 struct Instr {

@@ -75,7 +75,12 @@ static Instr decode(uint32_t w, uint32_t pc) {
         else if (f7 == 0x20 && f3 == 5) { fam = F_ALU; in.alu_op = ALU_SRA; }
         else if (f7 == 0x00) { static const int m0[8] = {F_ADD, -1, F_SLT, F_SLTU, F_XOR, -1, F_OR, F_AND}; fam = m0[f3]; }
         else if (f7 == 0x20) { fam = f3 == 0 ? F_SUB : -1; }
-        else if (f7 == 0x01) { fam = f3 == 0 ? F_MUL : f3 == 3 ? F_MULHU : -1; }
+        else if (f7 == 0x01) {  // M extension: MUL / MULHU in the cpu chip, the rest in the muldiv chip
+            static const uint32_t mop[8] = {0, ALU_MULH, ALU_MULHSU, 0, ALU_DIV, ALU_DIVU, ALU_REM, ALU_REMU};
+            if (f3 == 0) fam = F_MUL;
+            else if (f3 == 3) fam = F_MULHU;
+            else { fam = F_ALU; in.alu_op = mop[f3]; }
+        }
         if (fam < 0) in.supported = 0; else in.flags |= FL(fam);
         break;
     }
@@ -255,7 +260,19 @@ void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin
         else if (fl & FL(F_LUI)) a = in.imm;
         else if (fl & FL(F_ALU)) {
             const uint32_t sh = c & 31;
-            a = in.alu_op == ALU_SLL ? b << sh : in.alu_op == ALU_SRL ? b >> sh : (uint32_t)((int32_t)b >> sh);
+            const int32_t sb = (int32_t)b, sc = (int32_t)c;
+            switch (in.alu_op) {
+            case ALU_SLL: a = b << sh; break;
+            case ALU_SRL: a = b >> sh; break;
+            case ALU_SRA: a = (uint32_t)(sb >> sh); break;
+            case ALU_MULH: a = (uint32_t)(((int64_t)sb * (int64_t)sc) >> 32); break;
+            case ALU_MULHSU: a = (uint32_t)(((int64_t)sb * (int64_t)(uint64_t)c) >> 32); break;
+            // RISC-V: x / 0 = all ones, x % 0 = x; -2^31 / -1 = -2^31 remainder 0
+            case ALU_DIV: a = c == 0 ? 0xffffffffu : (b == 0x80000000u && c == 0xffffffffu) ? b : (uint32_t)(sb / sc); break;
+            case ALU_DIVU: a = c == 0 ? 0xffffffffu : b / c; break;
+            case ALU_REM: a = c == 0 ? b : (b == 0x80000000u && c == 0xffffffffu) ? 0u : (uint32_t)(sb % sc); break;
+            default: a = c == 0 ? b : b % c; break;  // ALU_REMU
+            }
             if (trace) R.shards.back().alu.push_back(AluEvent{in.alu_op, a, b, c});
         }
         else if (fl & FL(F_JAL)) { a = in.imm; next_pc = in.tgt; }
@@ -472,16 +489,18 @@ bool build_aux_host(const Program &prog, const ExecResult &res, size_t shard_pos
         }
     }
     // shift chip: one row per SLL/SRL/SRA of this shard (absent when the shard does not shift)
-    T.present[RV32_CHIP_SHIFT] = !S.alu.empty();
+    std::vector<AluEvent> shifts, muldivs;
+    for (auto &e : S.alu) (e.op <= ALU_SRA ? shifts : muldivs).push_back(e);
+    T.present[RV32_CHIP_SHIFT] = !shifts.empty();
     T.log_n[RV32_CHIP_SHIFT] = 0;
-    if (!S.alu.empty()) {
-        const uint32_t ls = ceil_log2(S.alu.size());
+    if (!shifts.empty()) {
+        const uint32_t ls = ceil_log2(shifts.size());
         const size_t ns = (size_t)1 << ls;
         T.log_n[RV32_CHIP_SHIFT] = ls;
         auto &H = T.main[RV32_CHIP_SHIFT];
         H.assign((size_t)RV32_SHIFT_MAIN_W * ns, 0);
-        for (size_t r = 0; r < S.alu.size(); r++) {
-            const AluEvent &e = S.alu[r];
+        for (size_t r = 0; r < shifts.size(); r++) {
+            const AluEvent &e = shifts[r];
             auto put = [&](int col, uint32_t v) { H[(size_t)col * ns + r] = v; };
             auto B = [](uint32_t w, int i) -> uint32_t { return (w >> (8 * i)) & 0xffu; };
             const uint32_t sh = e.c & 31, q = sh >> 3, rb = sh & 7, m = 1u << rb, mi = 1u << (8 - rb);
@@ -509,6 +528,98 @@ bool build_aux_host(const Program &prog, const ExecResult &res, size_t shard_pos
             sink.byte(B_RANGE - 1, (lo[0] << 8) | lo[1]); sink.byte(B_RANGE - 1, (lo[2] << 8) | lo[3]);
             sink.byte(B_RANGE - 1, (hi[0] << 8) | hi[1]); sink.byte(B_RANGE - 1, (hi[2] << 8) | hi[3]);
             if (e.op == ALU_SRA) sink.byte(B_MSB - 1, B(e.b, 3) << 8);
+        }
+    }
+    // muldiv chip: one row per MULH/MULHSU/DIV/DIVU/REM/REMU of this shard (absent when there is none);
+    // witness as tools/airgen/rv32.py:build_muldiv lays it out
+    T.present[RV32_CHIP_MULDIV] = !muldivs.empty();
+    T.log_n[RV32_CHIP_MULDIV] = 0;
+    if (!muldivs.empty()) {
+        const uint32_t ls = ceil_log2(muldivs.size());
+        const size_t ns = (size_t)1 << ls;
+        T.log_n[RV32_CHIP_MULDIV] = ls;
+        auto &H = T.main[RV32_CHIP_MULDIV];
+        H.assign((size_t)RV32_MULDIV_MAIN_W * ns, 0);
+        for (size_t row = 0; row < muldivs.size(); row++) {
+            const AluEvent &e = muldivs[row];
+            auto put = [&](int col, uint32_t v) { H[(size_t)col * ns + row] = v % P; };
+            auto B = [](uint32_t w, int i) -> uint32_t { return (w >> (8 * i)) & 0xffu; };
+            const bool is_mul = e.op == ALU_MULH || e.op == ALU_MULHSU, is_sdr = e.op == ALU_DIV || e.op == ALU_REM;
+            const bool is_dr = !is_mul;
+            static const int flag_col[10] = {0, 0, 0, 0, RV32_MULDIV_is_mulh, RV32_MULDIV_is_mulhsu, RV32_MULDIV_is_div, RV32_MULDIV_is_divu,
+                                             RV32_MULDIV_is_rem, RV32_MULDIV_is_remu};
+            put(RV32_MULDIV_is_real, 1);
+            put(flag_col[e.op], 1);
+            // quotient / remainder (divisions), X = b (multiplications)
+            uint32_t q = e.b, r = 0;
+            const bool c0 = is_dr && e.c == 0, ovf = is_sdr && e.b == 0x80000000u && e.c == 0xffffffffu;
+            if (is_dr) {
+                if (c0) { q = 0xffffffffu; r = e.b; }
+                else if (ovf) { q = e.b; r = 0; }
+                else if (is_sdr) { q = (uint32_t)((int32_t)e.b / (int32_t)e.c); r = (uint32_t)((int32_t)e.b % (int32_t)e.c); }
+                else { q = e.b / e.c; r = e.b % e.c; }
+            }
+            const uint32_t mx = q >> 31, my = e.c >> 31, mr = r >> 31, mb = e.b >> 31;
+            const uint32_t sx = mx & (uint32_t)(is_mul || is_sdr), sy = my & (uint32_t)(e.op == ALU_MULH || is_sdr);
+            const uint32_t sr = mr & (uint32_t)is_sdr, sb = mb & (uint32_t)is_sdr;
+            for (int i = 0; i < 4; i++) {
+                put(RV32_MULDIV_a_0 + i, B(e.a, i)); put(RV32_MULDIV_b_0 + i, B(e.b, i)); put(RV32_MULDIV_c_0 + i, B(e.c, i));
+                put(RV32_MULDIV_q_0 + i, B(q, i)); put(RV32_MULDIV_r_0 + i, B(r, i));
+            }
+            put(RV32_MULDIV_mx, mx); put(RV32_MULDIV_my, my); put(RV32_MULDIV_mr, mr); put(RV32_MULDIV_mb, mb);
+            put(RV32_MULDIV_sx, sx); put(RV32_MULDIV_sy, sy); put(RV32_MULDIV_sr, sr); put(RV32_MULDIV_sb, sb);
+            sink.byte(B_MSB - 1, B(q, 3) << 8); sink.byte(B_MSB - 1, B(e.c, 3) << 8);
+            sink.byte(B_MSB - 1, B(r, 3) << 8); sink.byte(B_MSB - 1, B(e.b, 3) << 8);
+            // unsigned product bytes and carries
+            uint32_t prod[8], carry = 0;
+            for (int k = 0; k < 8; k++) {
+                uint32_t t = carry;
+                for (int i = 0; i < 4; i++) if (k - i >= 0 && k - i < 4) t += B(q, i) * B(e.c, k - i);
+                prod[k] = t & 0xff; carry = t >> 8;
+                put(RV32_MULDIV_prod_0 + k, prod[k]); put(RV32_MULDIV_mcy_0 + k, carry);
+                sink.byte(B_U16 - 1, carry);
+            }
+            for (int k = 0; k < 4; k++) sink.byte(B_RANGE - 1, (prod[2 * k] << 8) | prod[2 * k + 1]);
+            // high word of the signed product with borrows 0..2
+            uint32_t h[4], bin = 0;
+            for (int i = 0; i < 4; i++) {
+                int32_t t = (int32_t)prod[4 + i] - (int32_t)(sx * B(e.c, i)) - (int32_t)(sy * B(q, i)) - (int32_t)bin;
+                uint32_t bo = 0;
+                while (t < 0) { t += 256; bo++; }
+                h[i] = (uint32_t)t; bin = bo;
+                put(RV32_MULDIV_h_0 + i, h[i]); put(RV32_MULDIV_bw_0 + i, bo);
+            }
+            sink.byte(B_RANGE - 1, (h[0] << 8) | h[1]); sink.byte(B_RANGE - 1, (h[2] << 8) | h[3]);
+            sink.byte(B_RANGE - 1, (B(q, 0) << 8) | B(q, 1)); sink.byte(B_RANGE - 1, (B(q, 2) << 8) | B(q, 3));
+            sink.byte(B_RANGE - 1, (B(r, 0) << 8) | B(r, 1)); sink.byte(B_RANGE - 1, (B(r, 2) << 8) | B(r, 3));
+            uint32_t dl0 = 0, dl1 = 0;
+            if (is_dr) {
+                put(RV32_MULDIV_is_c0, c0); put(RV32_MULDIV_is_ovf, ovf);
+                const uint32_t csum = B(e.c, 0) + B(e.c, 1) + B(e.c, 2) + B(e.c, 3);
+                if (csum) put(RV32_MULDIV_cinv, inv(Fp::from_canonical(csum)).canonical());
+                if (!ovf) {  // 64-bit sum P + R' = B' in 16-bit limbs
+                    const uint32_t Pl[4] = {prod[0] | (prod[1] << 8), prod[2] | (prod[3] << 8), h[0] | (h[1] << 8), h[2] | (h[3] << 8)};
+                    const uint32_t Rl[4] = {r & 0xffff, r >> 16, 65535 * sr, 65535 * sr};
+                    uint32_t cy = 0;
+                    for (int k = 0; k < 4; k++) { cy = (Pl[k] + Rl[k] + cy) >> 16; put(RV32_MULDIV_dcy_0 + k, cy); }
+                }
+                if (!c0) {  // |c| - |r| - 1 in two limbs, low-limb carry e0 = ea + 2 eb - 1
+                    const int64_t sc_ = 1 - 2 * (int64_t)sy, sr_ = 1 - 2 * (int64_t)sr;
+                    const int64_t t0 = sc_ * (e.c & 0xffff) - sr_ * (r & 0xffff) - 1;
+                    int64_t e0 = 0;
+                    while (t0 + 65536 * e0 < 0) e0++;
+                    while (t0 + 65536 * e0 > 65535) e0--;
+                    dl0 = (uint32_t)(t0 + 65536 * e0);
+                    dl1 = (uint32_t)(sc_ * (e.c >> 16) - sr_ * (r >> 16) + 65536 * ((int64_t)sy - (int64_t)sr) - e0);
+                    put(RV32_MULDIV_ea, (uint32_t)((e0 + 1) & 1)); put(RV32_MULDIV_eb, (uint32_t)((e0 + 1) >> 1));
+                } else {
+                    put(RV32_MULDIV_ea, 1);  // e0 = 0 (unconstrained here; any boolean pair is fine)
+                }
+            } else {
+                put(RV32_MULDIV_ea, 1);
+            }
+            put(RV32_MULDIV_dl_0, dl0); put(RV32_MULDIV_dl_1, dl1);
+            sink.byte(B_U16 - 1, dl0); sink.byte(B_U16 - 1, dl1);
         }
     }
     const uint32_t lp = prep.log_n[RV32_CHIP_PROGRAM];

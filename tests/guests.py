@@ -182,13 +182,59 @@ def exit_with(code):
 
 
 def uses_unprovable():
-    """retires an instruction that executes but has no chip yet (DIV)"""
+    """retires an instruction that executes but that no chip proves (FENCE; every RV32IM computational
+    instruction has a chip)"""
     a = Asm()
     a.li("a3", 77)
-    a.li("a4", 5)
-    a.div("a3", "a3", "a4")
+    a.word(0x0000000F)      # fence
     a.halt(0)
     return a.elf()
+
+
+def muldiv():
+    """MULH / MULHSU / DIV / DIVU / REM / REMU over sign-critical operands, including RISC-V's special cases:
+    division by zero (quotient all ones, remainder = dividend) and the signed overflow -2^31 / -1"""
+    vals = [0, 1, 2, 7, 0x7FFFFFFF, 0x80000000, 0x80000001, 0xFFFFFFFF, 0xFFFFFFFE, 0x12345678, 0xDEADBEEF, 0x00010000, 0xFFFF0001, 100, 0xFFFFFF9C]
+    sx = lambda v: v - (1 << 32) if v >> 31 else v
+
+    def tdiv(x, y):     # C-style truncating division
+        q = abs(x) // abs(y)
+        return -q if (x < 0) != (y < 0) else q
+
+    def ref(op, b, c):
+        if op == "mulh":
+            return ((sx(b) * sx(c)) >> 32) & M32
+        if op == "mulhsu":
+            return ((sx(b) * c) >> 32) & M32
+        if op == "divu":
+            return M32 if c == 0 else b // c
+        if op == "remu":
+            return b if c == 0 else b % c
+        if c == 0:
+            return M32 if op == "div" else b
+        if b == 0x80000000 and c == 0xFFFFFFFF:
+            return b if op == "div" else 0
+        q = tdiv(sx(b), sx(c))
+        return (q if op == "div" else sx(b) - q * sx(c)) & M32
+
+    ops = ["mulh", "mulhsu", "div", "divu", "rem", "remu"]
+    pairs = [(b, c) for b in vals for c in vals]
+    a = Asm()
+    out = a.dword("out", [0] * (len(pairs) * len(ops) + 4))
+    a.li("s0", out)
+    exp = []
+    for b, c in pairs:
+        a.li("a3", b)
+        a.li("a4", c)
+        for op in ops:
+            getattr(a, op)("a5", "a3", "a4")
+            a.sw("a5", "s0", 0)
+            a.addi("s0", "s0", 4)
+            exp.append(ref(op, b, c))
+    a.li("s1", out)
+    _write_pv(a, "s1", 4 * len(exp))
+    a.halt(0)
+    return a.elf(), b"".join(struct.pack("<I", v) for v in exp)
 
 
 def shifts():

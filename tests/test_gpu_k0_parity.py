@@ -11,15 +11,15 @@ from tests import guests
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("which,log_shard", [("arith", 21), ("bignum", 21), ("hint", 21), ("bignum", 8), ("subword", 21), ("shifts", 8)])
+@pytest.mark.parametrize("which,log_shard", [("arith", 21), ("bignum", 21), ("hint", 21), ("bignum", 8), ("subword", 21), ("shifts", 8), ("muldiv", 9)])
 def test_k0_device_traces_equal_host_traces(which, log_shard):
     from dvt_circuits_amd import capi
 
     stdin = []
     if which == "arith":
         elf = guests.arith()[0]
-    elif which == "shifts":
-        elf = guests.shifts()[0]
+    elif which in ("shifts", "muldiv"):
+        elf = getattr(guests, which)()[0]
     elif which == "subword":
         elf = guests.subword()[0]
     elif which == "bignum":

@@ -64,11 +64,11 @@ def test_toy_proof_bytes_equal_oracle(shape):
     p.close()
 
 
-@pytest.mark.parametrize("log_shard,which", [(21, "bignum"), (8, "bignum"), (9, "shifts")])
+@pytest.mark.parametrize("log_shard,which", [(21, "bignum"), (8, "bignum"), (9, "shifts"), (10, "muldiv")])
 def test_rv32_proof_bytes_equal_oracle(log_shard, which):
     from dvt_circuits_amd import capi
 
-    elf, want = guests.bignum(2, limbs=3) if which == "bignum" else guests.shifts()
+    elf, want = guests.bignum(2, limbs=3) if which == "bignum" else getattr(guests, which)()
     p = capi.Prover('{"fri_queries": %d, "pow_bits": %d, "log_shard_size": %d}' % (Q, POW, log_shard))
     pk, vk = p.setup(elf)
     proof, rep = p.prove_core(pk)

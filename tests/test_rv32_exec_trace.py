@@ -84,6 +84,15 @@ def test_shift_guest(air):
     check_traces(air, elf, log_shard=7)   # shards with and without shift rows
 
 
+def test_muldiv_guest(air):
+    elf, want = guests.muldiv()
+    rc, rep, pv, err = capi.execute(elf)
+    assert rc == 0 and not rep["unprovable"], err
+    assert pv == want
+    check_traces(air, elf)
+    check_traces(air, elf, log_shard=9)   # shards with and without muldiv rows
+
+
 def test_hint_guest(air):
     elf = guests.hint_sum()
     data = struct.pack("<8I", *range(100, 108))
@@ -130,3 +139,43 @@ def test_tampered_trace_is_caught_by_oracle(air):
     # a wrong claimed public value unbalances the public-values bus
     bad = [(b, v if i else [v[0], (v[1] + 1) % 256] + v[2:], s_, m) for i, (b, v, s_, m) in enumerate(extra)]
     assert air.logup_unbalanced(chips, pubs, extra=bad)[0] == 2
+
+
+def test_every_muldiv_witness_cell_is_pinned(air):
+    """soundness smoke test of the muldiv AIR (an original design, so there is no reference behaviour to lean on):
+    changing any single witness cell of a row must break a constraint or the LogUp balance, except where the AIR
+    documents the cell as unused for that operation (the divisor inverse on multiplication rows)"""
+    from tools.rvasm import Asm
+
+    cases = [("mulh", 0x80000001, 0x7FFFFFFF), ("mulhsu", 0xFFFFFFFE, 0xFFFFFFFF), ("div", 0xFFFFFF9C, 7), ("divu", 100, 7),
+             ("rem", 0xFFFFFF9C, 0xFFFFFFF9), ("remu", 0xDEADBEEF, 0x10000), ("div", 5, 0), ("rem", 0x80000000, 0xFFFFFFFF)]
+    a = Asm()
+    for op, b, c in cases:
+        a.li("a3", b)
+        a.li("a4", c)
+        getattr(a, op)("a5", "a3", "a4")
+    a.halt(0)
+    elf = a.elf()
+    chips, pubs, _ = capi.rv32_debug_traces(elf)
+    md = next(c for c in chips if air.chip(c["chip_id"]).name == b"muldiv")
+    assert air.check_constraints(md["chip_id"], md["main"], md["prep"], pubs)[0] == 0
+    assert air.logup_unbalanced(chips, pubs)[0] == 0
+    W = md["main"].shape[0]
+    names = {60: "cinv", 64: "ea", 65: "eb", 66: "dcy", 67: "dcy", 68: "dcy", 69: "dcy"}
+    free = set()
+    for row, (op, b, c) in enumerate(cases):
+        for col in range(W):
+            m = md["main"].copy()
+            m[col, row] = (int(m[col, row]) + 1) % 2013265921
+            if air.check_constraints(md["chip_id"], m, md["prep"], pubs)[0]:
+                continue
+            forged = dict(md, main=m)
+            if air.logup_unbalanced([forged if ch is md else ch for ch in chips], pubs)[0]:
+                continue
+            free.add((row, names.get(col, col)))
+    # cells the AIR leaves open because nothing reads them for that operation: on multiplication rows the divisor
+    # inverse, the comparison carry and the 64-bit addition carries; the comparison carry when dividing by zero (the
+    # comparison is waived); the addition carries on the overflow row (the addition is waived)
+    # (and the "inverse" of a zero divisor)
+    want = {(r, n) for r in (0, 1) for n in ("cinv", "eb", "dcy")} | {(6, "eb"), (6, "cinv")} | {(7, "dcy")}
+    assert free == want, sorted(free ^ want, key=str)

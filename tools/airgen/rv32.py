@@ -11,6 +11,7 @@ Chips
   mem_init  one row per initialised address, sorted: initial value at timestamp 0,
             final value/timestamp; image words are bound to mem_image
   shift     SLL/SRL/SRA rows, fed by the cpu chip over the alu bus (only in shards that shift)
+  muldiv    MULH/MULHSU/DIV/DIVU/REM/REMU rows, same bus (only in shards that use them)
 
 Memory consistency is an offline-checking LogUp multiset over tuples
 (addr, byte0..3, timestamp): every access consumes the previous tuple of its
@@ -32,6 +33,7 @@ from .dsl import Chip, Expr, Machine, esum, word
 
 BUSES = {"program": 1, "byte": 2, "mem": 3, "image": 4, "pv": 5, "alu": 6}
 ALU_SLL, ALU_SRL, ALU_SRA = 1, 2, 3
+ALU_MULH, ALU_MULHSU, ALU_DIV, ALU_DIVU, ALU_REM, ALU_REMU = 4, 5, 6, 7, 8, 9
 SYS_COMMIT = 0x10
 
 # byte-table opcodes
@@ -353,6 +355,116 @@ def build_shift():
     return ch
 
 
+def build_muldiv():
+    """MULH / MULHSU / DIV / DIVU / REM / REMU rows received from the cpu chip over the alu bus.
+    One relation serves all six: X * Y (+ R) = B as two's-complement 64-bit numbers, with
+      multiplications:  X = b, Y = c, result a = high word of the product
+      divisions:        X = quotient q, Y = c, R = remainder r, B = dividend b;  a = q or r.
+    The unsigned 64-bit product of the words is built from bytes (as the cpu chip's MUL family does); sign extension
+    of X (flag sx) and Y (sy) only changes the high word: hi = prod_hi - sx * Y - sy * X (mod 2^32).
+    Division: q * c + r = b holds over the integers (|q c| < 2^62, no wrap), |r| < |c| and sign(r) = sign(b) pin q and r;
+    RISC-V's two special cases are flags: c = 0 (q = all ones, r = b falls out of the equation) and the signed overflow
+    -2^31 / -1 (q = -2^31, r = 0, the equation is waived)."""
+    ch = Chip("muldiv")
+    is_real = ch.col("is_real")
+    names = ["mulh", "mulhsu", "div", "divu", "rem", "remu"]
+    f = {n: ch.col("is_" + n) for n in names}
+    a, b, c = ch.cols("a", 4), ch.cols("b", 4), ch.cols("c", 4)
+    q, r = ch.cols("q", 4), ch.cols("r", 4)
+    prod, mcy = ch.cols("prod", 8), ch.cols("mcy", 8)
+    h, bw = ch.cols("h", 4), ch.cols("bw", 4)
+    mx, my, mr, mb = ch.col("mx"), ch.col("my"), ch.col("mr"), ch.col("mb")      # top bits of q3, c3, r3, b3
+    sx, sy, sr, sb = ch.col("sx"), ch.col("sy"), ch.col("sr"), ch.col("sb")      # ... where the operation reads them as signs
+    is_c0, cinv, is_ovf = ch.col("is_c0"), ch.col("cinv"), ch.col("is_ovf")
+    dl, ea, eb = ch.cols("dl", 2), ch.col("ea"), ch.col("eb")
+    dcy = ch.cols("dcy", 4)
+
+    ch.assert_bool(is_real)
+    for n in names:
+        ch.assert_bool(f[n])
+    ch.assert_eq(esum(f.values()), is_real)
+    codes = dict(mulh=ALU_MULH, mulhsu=ALU_MULHSU, div=ALU_DIV, divu=ALU_DIVU, rem=ALU_REM, remu=ALU_REMU)
+    ch.receive("alu", [esum(codes[n] * f[n] for n in names)] + a + b + c, is_real)
+    is_mul = f["mulh"] + f["mulhsu"]
+    is_dr = f["div"] + f["divu"] + f["rem"] + f["remu"]
+    is_sdr = f["div"] + f["rem"]
+
+    # operands and results
+    for i in range(4):
+        ch.assert_zero(is_mul * (q[i] - b[i]))                   # X = b for multiplications
+        ch.assert_zero(is_mul * (a[i] - h[i]))
+        ch.assert_zero((f["div"] + f["divu"]) * (a[i] - q[i]))
+        ch.assert_zero((f["rem"] + f["remu"]) * (a[i] - r[i]))
+    # signs: top bits from the byte table, used only where the operation is signed
+    ch.send("byte", [B_MSB, mx, q[3], 0], is_real)
+    ch.send("byte", [B_MSB, my, c[3], 0], is_real)
+    ch.send("byte", [B_MSB, mr, r[3], 0], is_real)
+    ch.send("byte", [B_MSB, mb, b[3], 0], is_real)
+    ch.assert_eq(sx, mx * (is_mul + is_sdr))
+    ch.assert_eq(sy, my * (f["mulh"] + is_sdr))
+    ch.assert_eq(sr, mr * is_sdr)
+    ch.assert_eq(sb, mb * is_sdr)
+
+    # unsigned product X * Y: 8 bytes + carries
+    for k in range(8):
+        terms = esum(q[i] * c[k - i] for i in range(4) if 0 <= k - i < 4)
+        cin = mcy[k - 1] if k else Expr.const(0)
+        ch.assert_zero(terms + cin - prod[k] - 256 * mcy[k])
+    for k in range(4):
+        ch.send("byte", [B_RANGE, 0, prod[2 * k], prod[2 * k + 1]], is_real)
+    for k in range(8):
+        ch.send("byte", [B_U16, 0, mcy[k], 0], is_real)
+    # high word of the signed product: h = prod_hi - sx * Y - sy * X (mod 2^32), borrows 0..2
+    for i in range(4):
+        bin_ = bw[i - 1] if i else Expr.const(0)
+        ch.assert_zero(prod[4 + i] - sx * c[i] - sy * q[i] - bin_ + 256 * bw[i] - h[i])
+        ch.assert_zero(bw[i] * (bw[i] - 1) * (bw[i] - 2))
+    ch.send("byte", [B_RANGE, 0, h[0], h[1]], is_real)
+    ch.send("byte", [B_RANGE, 0, h[2], h[3]], is_real)
+    ch.send("byte", [B_RANGE, 0, q[0], q[1]], is_real)
+    ch.send("byte", [B_RANGE, 0, q[2], q[3]], is_real)
+    ch.send("byte", [B_RANGE, 0, r[0], r[1]], is_real)
+    ch.send("byte", [B_RANGE, 0, r[2], r[3]], is_real)
+
+    # ---- divisions
+    csum = esum(c)
+    ch.assert_bool(is_c0)
+    ch.assert_bool(is_ovf)
+    ch.assert_zero(is_c0 * (1 - is_dr))
+    ch.assert_zero(is_ovf * (1 - is_sdr))
+    ch.assert_zero(is_c0 * csum)
+    ch.assert_zero(is_dr * (csum * cinv - (1 - is_c0)))
+    for i in range(4):
+        ch.assert_zero(is_c0 * (q[i] - 255))                     # x / 0 = all ones
+        ch.assert_zero(is_ovf * (c[i] - 255))                    # -2^31 / -1 = -2^31 remainder 0
+        ch.assert_zero(is_ovf * (b[i] - (128 if i == 3 else 0)))
+        ch.assert_zero(is_ovf * (q[i] - b[i]))
+        ch.assert_zero(is_ovf * r[i])
+    # q * c + r = b as 64-bit two's-complement numbers, in 16-bit limbs (the field holds < 2^31)
+    P = [prod[0] + 256 * prod[1], prod[2] + 256 * prod[3], h[0] + 256 * h[1], h[2] + 256 * h[3]]
+    R = [r[0] + 256 * r[1], r[2] + 256 * r[3], 65535 * sr, 65535 * sr]
+    Bv = [b[0] + 256 * b[1], b[2] + 256 * b[3], 65535 * sb, 65535 * sb]
+    for k in range(4):
+        cin = dcy[k - 1] if k else Expr.const(0)
+        ch.assert_zero((is_dr - is_ovf) * (P[k] + R[k] + cin - Bv[k] - 65536 * dcy[k]))
+        ch.assert_bool(dcy[k])
+    # sign(r) = sign(b) unless r = 0
+    for i in range(4):
+        ch.assert_zero(is_dr * ((sr - sb) * r[i]))
+    # |r| < |c|:  |c| - |r| - 1 = dl (two 16-bit limbs), |v| = (1 - 2 s_v) v + s_v 2^32
+    # (low-limb carry e0 = ea + 2 eb - 1 in {-1, 0, 1, 2}: the low limbs span [-131071, 131069])
+    sc_, sr_ = 1 - 2 * sy, 1 - 2 * sr
+    sel_lt = is_dr - is_c0
+    e0 = ea + 2 * eb - 1
+    ch.assert_bool(ea)
+    ch.assert_bool(eb)
+    ch.assert_zero(sel_lt * (sc_ * (c[0] + 256 * c[1]) - sr_ * (r[0] + 256 * r[1]) - 1 + 65536 * e0 - dl[0]))
+    ch.assert_zero(sel_lt * (sc_ * (c[2] + 256 * c[3]) - sr_ * (r[2] + 256 * r[3]) + 65536 * (sy - sr) - e0 - dl[1]))
+    ch.send("byte", [B_U16, 0, dl[0], 0], is_real)
+    ch.send("byte", [B_U16, 0, dl[1], 0], is_real)
+    return ch
+
+
 def build_mem_image():
     ch = Chip("mem_image")
     addr, v, real = ch.prep("addr"), ch.preps("v", 4), ch.prep("is_real")
@@ -386,4 +498,4 @@ def build_mem_init():
 
 
 def build():
-    return Machine("rv32", [build_program(), build_byte(), build_cpu(), build_mem_image(), build_mem_init(), build_shift()], BUSES)
+    return Machine("rv32", [build_program(), build_byte(), build_cpu(), build_mem_image(), build_mem_init(), build_shift(), build_muldiv()], BUSES)
