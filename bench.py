@@ -2,9 +2,12 @@
 """Benchmark of the hot path named by BASELINE.json: prover guest-cycles/second
 (and proofs/hour) on MI355X.
 
-A "step" = one proof of one execution of the synthetic DKG-like guest
-(tests/guests.py:bignum): K0 trace expansion .. K9 FRI queries over all its shards
-of 2^21 RV32IM cycles, with the compact execution records already resident in HBM.
+A "step" = one proof of one execution of the finalization-shaped guest
+(tests/guests.py:finalization_like) on the reference's examples/finalization_test.json
+(kept as tests/golden/finalization_example.json), encoded exactly as the reference's
+host encodes it (typed JSON -> CBOR -> one SP1Stdin buffer, src/main.rs:451-460):
+K0 trace expansion .. K9 FRI queries over all its shards of 2^21 RV32IM cycles,
+with the compact execution records already resident in HBM.
 The execution has shards_per_gpu x N shards (weak scaling: N = 1 is the single-shard
 configuration BASELINE.json quotes); shard i is proven on GPU i mod N.  The only
 exchange is an all-gather of the 60-byte shard headers (main-trace root + public
@@ -34,16 +37,25 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 
 
+def workload_stdin():
+    """the reference's own example input through the reference's host-side encoding"""
+    from dvt_circuits_amd import capi
+
+    with open(os.path.join(ROOT, "tests", "golden", "finalization_example.json"), "rb") as f:
+        return capi.stdin_from_json("finalization", f.read())
+
+
 def cpu_baseline(small_iters, big_iters):
     """Oracle CPU prover on two bounded samples of the same workload (rank 0, N = 1 only)."""
     from dvt_circuits_amd import capi
     from tests import _oracle_prover, guests
 
+    buf = workload_stdin()
     pts = []
     for it in (small_iters, big_iters):
-        elf, _ = guests.bignum(it)
-        chips, pubs, _ = capi.rv32_debug_traces(elf)
-        cyc = capi.execute(elf)[1]["cycles"]
+        elf, _ = guests.finalization_like(it, buf)
+        chips, pubs, _ = capi.rv32_debug_traces(elf, [buf])
+        cyc = capi.execute(elf, [buf])[1]["cycles"]
         t = time.perf_counter()
         gc = _oracle_prover.global_challenges(_oracle_prover.prep_root_of(chips), [_oracle_prover.main_root(chips) + [int(x) for x in pubs]])
         _oracle_prover.prove_shard("rv32", chips, pubs, 100, 4, perm_challenges=gc)
@@ -69,7 +81,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--iters", type=int, default=0, help="bignum guest iterations (default 907 per shard: ~2.096M cycles fill one 2^21-cycle shard)")
+    ap.add_argument("--iters", type=int, default=0, help="multiply-accumulate iterations of the guest (default 907 per shard - 3: ~2.096M cycles fill one 2^21-cycle shard)")
     ap.add_argument("--shards-per-gpu", type=int, default=1, help="weak scaling: the execution has shards_per_gpu x n_gpus shards")
     ap.add_argument("--cpu-small", type=int, default=112)
     ap.add_argument("--cpu-big", type=int, default=224)
@@ -96,12 +108,13 @@ def main():
 
     # workload: one execution of (shards_per_gpu x world) shards of 2^21 cycles; rank r owns shards r, r+world, ...
     total_shards = args.shards_per_gpu * world
-    iters = args.iters if args.iters else 907 * total_shards
-    elf, want_pv = guests.bignum(iters)
+    iters = args.iters if args.iters else 907 * total_shards - 3
+    stdin_buf = workload_stdin()
+    elf, want_pv = guests.finalization_like(iters, stdin_buf)
     prover = capi.Prover('{"device": %d, "fri_queries": 100, "pow_bits": 16, "log_shard_size": 21}' % local)
     pk, vk = prover.setup(elf)
     t_host = time.perf_counter()
-    job, rep = prover.prepare(pk)
+    job, rep = prover.prepare(pk, [stdin_buf])
     t_host = time.perf_counter() - t_host
     cycles = int(rep["cycles"])
     n_shards = prover.job_shards(job)
@@ -161,7 +174,7 @@ def main():
     e2e = None
     if world == 1:
         t1 = time.perf_counter()
-        j2, _ = prover.prepare(pk)
+        j2, _ = prover.prepare(pk, [stdin_buf])
         prover.prove_job(pk, j2, want_bytes=False)
         prover.sync()
         e2e = time.perf_counter() - t1
@@ -169,9 +182,9 @@ def main():
 
     # kernel-family timing on a profiled handle (HIP events on the prover stream, same shard)
     prof = capi.Prover('{"device": %d, "fri_queries": 100, "pow_bits": 16, "profile": 1}' % local)
-    pelf, _ = guests.bignum(907)           # one shard
+    pelf, _ = guests.finalization_like(904, stdin_buf)           # one shard
     ppk, _ = prof.setup(pelf)
-    pjob, _ = prof.prepare(ppk)
+    pjob, _ = prof.prepare(ppk, [stdin_buf])
     prof.prove_job(ppk, pjob, want_bytes=False)
     prof.prove_job(ppk, pjob, want_bytes=False)
     stage = prof.stage_ms()
@@ -184,7 +197,7 @@ def main():
     shard_alg = 36 * ks["cells_main"] + 36 * ks["cells_perm"] + 28 * ks["cells_quotient"] + 24 * ks["cells_prep"]
     step_s = dt / args.steps / max(len(mine), 1)
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_k1_traffic.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1b_pmc_k1_traffic.json")))
     except OSError:
         pmc = {}
 
@@ -202,8 +215,11 @@ def main():
         "dtype": "u32",
         "data": "synthetic",
         "config": {
-            "workload": "finalization-like synthetic DKG guest (tests/guests.py:bignum, 384-bit multiply-accumulate), one shard of "
-                        "~2^21 RV32IM cycles, BASELINE configs[1]; the reference's own guest ELF is prebuilt machine code and is not run",
+            "workload": "BASELINE configs[1]: examples/finalization_test.json (tests/golden/finalization_example.json) through the reference's "
+                        "JSON -> CBOR -> SP1Stdin encoding, proven by the finalization-shaped synthetic guest (tests/guests.py:finalization_like: "
+                        "reads the buffer, 384-bit multiply-accumulate seeded by it), one shard of ~2^21 RV32IM cycles; the reference's own guest "
+                        "ELF is prebuilt machine code and is not run",
+            "stdin_bytes": len(stdin_buf),
             "guest_cycles_per_proof": cycles,
             "shards_per_proof": n_shards,
             "shards_per_gpu": args.shards_per_gpu,
@@ -223,7 +239,7 @@ def main():
             "unit": "GB/s",
             "frac": lde_gbps / HBM_PEAK_GBPS,
             "traffic": pmc.get("k1_hbm_bytes_per_proof"),
-            "traffic_source": "profiles/r1_pmc_k1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this command, "
+            "traffic_source": "profiles/r1b_pmc_k1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this command, "
                               "gfx950 FETCH_SIZE x2 correction applied where the guide prescribes it); bytes per proof, like alg_bytes_per_proof",
             "alg_bytes_per_proof": ks["lde_alg_bytes"],
             "ms_per_proof": ks["lde_ms"],

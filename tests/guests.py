@@ -80,13 +80,14 @@ def arith():
     return a.elf(), b"".join(struct.pack("<I", v) for v in exp)
 
 
-def bignum(iters, limbs=12):
-    """t += a * b (schoolbook, `limbs` x `limbs` words) repeated `iters` times; returns (elf, expected public values)."""
+def _bignum_consts(limbs):
     A = [(0x9E3779B9 * (i + 1)) & M32 for i in range(limbs)]
     B = [(0x85EBCA6B * (i + 3) + 7) & M32 for i in range(limbs)]
-    a = Asm()
-    pa, pb = a.dword("a", A), a.dword("b", B)
-    pt = a.dword("t", [0] * (2 * limbs + 1))
+    return A, B
+
+
+def _bignum_loop(a, pa, pb, pt, iters, limbs):
+    """emit: t += a * b (schoolbook, `limbs` x `limbs` words) repeated `iters` times, then commit t and halt"""
     a.li("s0", iters)
     a.label("outer")
     a.li("s1", pb)                 # &b[i]
@@ -126,7 +127,10 @@ def bignum(iters, limbs=12):
     a.li("s1", pt)
     _write_pv(a, "s1", 4 * 2 * limbs)
     a.halt(0)
-    # expected: the same word-level algorithm in Python (the carry out of t[i+limbs] is dropped, as in the guest)
+
+
+def _bignum_expected(A, B, iters, limbs):
+    """the same word-level algorithm in Python (the carry out of t[i+limbs] is dropped, as in the guest)"""
     t = [0] * (2 * limbs + 1)
     for _ in range(iters):
         for i in range(limbs):
@@ -141,8 +145,67 @@ def bignum(iters, limbs=12):
                 t[i + j] = v2
                 carry = (hi + c1 + c2) & M32
             t[i + limbs] = (t[i + limbs] + carry) & M32
-    exp = b"".join(struct.pack("<I", t[i]) for i in range(2 * limbs))
-    return a.elf(), exp
+    return b"".join(struct.pack("<I", t[i]) for i in range(2 * limbs))
+
+
+def bignum(iters, limbs=12):
+    """t += a * b (schoolbook, `limbs` x `limbs` words) repeated `iters` times; returns (elf, expected public values)."""
+    A, B = _bignum_consts(limbs)
+    a = Asm()
+    pa, pb = a.dword("a", A), a.dword("b", B)
+    pt = a.dword("t", [0] * (2 * limbs + 1))
+    _bignum_loop(a, pa, pb, pt, iters, limbs)
+    return a.elf(), _bignum_expected(A, B, iters, limbs)
+
+
+def finalization_like(iters, stdin_buf: bytes, limbs=12):
+    """The benchmark workload in the shape of the reference's finalization guest (crates/finalization_prove/src/main.rs:
+    read ONE stdin buffer, do multi-limb field arithmetic seeded by it, commit the results): reads the buffer through
+    HINT_LEN / HINT_READ, folds every input word into the operands (a[k mod limbs] += w_k, b[(k + limbs/2) mod limbs] ^= w_k),
+    then runs the 384-bit multiply-accumulate of `bignum`.  Returns (elf, expected public values for `stdin_buf`)."""
+    A, B = _bignum_consts(limbs)
+    a = Asm()
+    pa, pb = a.dword("a", A), a.dword("b", B)
+    pt = a.dword("t", [0] * (2 * limbs + 1))
+    a.li("t0", SYS_HINT_LEN)
+    a.ecall()                      # t0 <- length
+    a.mv("s1", "t0")
+    a.li("a0", HEAP)
+    a.mv("a1", "s1")
+    a.li("t0", SYS_HINT_READ)
+    a.ecall()
+    a.li("s2", HEAP)
+    a.add("s3", "s2", "s1")        # end of the input
+    a.li("s4", pa)                 # cursor in a
+    a.li("s5", pa + 4 * limbs)
+    a.li("s6", pb + 4 * (limbs // 2))   # cursor in b
+    a.li("s7", pb + 4 * limbs)
+    a.beq("s2", "s3", "folded")
+    a.label("fold")
+    a.lw("a4", "s2", 0)
+    a.lw("a5", "s4", 0)
+    a.add("a5", "a5", "a4")
+    a.sw("a5", "s4", 0)
+    a.lw("a5", "s6", 0)
+    a.xor("a5", "a5", "a4")
+    a.sw("a5", "s6", 0)
+    a.addi("s4", "s4", 4)
+    a.bne("s4", "s5", "fa")
+    a.li("s4", pa)
+    a.label("fa")
+    a.addi("s6", "s6", 4)
+    a.bne("s6", "s7", "fb")
+    a.li("s6", pb)
+    a.label("fb")
+    a.addi("s2", "s2", 4)
+    a.bltu("s2", "s3", "fold")
+    a.label("folded")
+    _bignum_loop(a, pa, pb, pt, iters, limbs)
+    padded = stdin_buf + b"\0" * (-len(stdin_buf) % 4)
+    for k, (w,) in enumerate(struct.iter_unpack("<I", padded)):
+        A[k % limbs] = (A[k % limbs] + w) & M32
+        B[(k + limbs // 2) % limbs] ^= w
+    return a.elf(), _bignum_expected(A, B, iters, limbs)
 
 
 def hint_sum():
