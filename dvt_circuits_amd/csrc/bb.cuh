@@ -86,6 +86,12 @@ DVT_HD Fp inv(Fp a) { return pow(a, P - 2); }
 inline Fp two_adic_generator(unsigned k) { return pow(Fp::from_canonical(31), (uint64_t)(P - 1) >> k); }
 constexpr uint32_t COSET_SHIFT = 31;
 
+// the representative of a in (-p/2, p/2], exact in a double (operand format of the FP64 dot-product kernels)
+inline double centred_canonical(Fp a) {
+    const uint32_t c = a.canonical();
+    return c > P / 2 ? (double)c - (double)P : (double)c;
+}
+
 // ---- F_{p^4} = F_p[x]/(x^4 - 11) ----
 struct Fp4 {
     Fp c[4];

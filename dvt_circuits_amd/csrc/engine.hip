@@ -575,28 +575,29 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
         ALLOC(d_w, Fp4, (size_t)1 << max_log_n);
         size_t max_cols = 8;
         for (auto &s : cs) max_cols = std::max<size_t>({max_cols, (size_t)s.d->main_w, (size_t)4 * s.d->perm_ext_w, (size_t)s.d->prep_w});
+        // every matrix writes its opened values into one result buffer; ONE download after the last launch
+        // (a host synchronisation per matrix costs more than the small chips' kernels)
+        size_t total_vals = 0;
+        for (auto &s : cs) total_vals += 2 * ((size_t)s.d->prep_w + s.d->main_w + 4 * s.d->perm_ext_w + 8);
         Fp4 *d_partial, *d_res;
-        ALLOC(d_partial, Fp4, (size_t)64 * max_cols * 2);
-        ALLOC(d_res, Fp4, max_cols * 2);
-        std::vector<Fp4> host_res(max_cols * 2);
-        std::map<uint32_t, bool> weights_ready;
+        ALLOC(d_partial, Fp4, (size_t)OPEN_MAX_ROW_BLOCKS * max_cols * 2);
+        ALLOC(d_res, Fp4, total_vals);
+        struct Pending { size_t off; uint32_t width; Fp4 scale; std::vector<Fp4> *local, *next; };
+        std::vector<Pending> pending;
+        size_t res_off = 0;
         auto open_matrix = [&](const uint32_t *base, uint32_t width, const ChipState &s, Fp4 scale, std::vector<Fp4> *local,
                                std::vector<Fp4> *next) -> bool {
             std::vector<uint64_t> ptrs(width);
             for (uint32_t c = 0; c < width; c++) ptrs[c] = (uint64_t)(uintptr_t)(base + (size_t)c * s.n);
             auto d_cols = reinterpret_cast<const uint32_t *const *>(upload(ptrs.data(), width * 8));
             if (!d_cols) return false;
-            HIPCHK(launch_open_columns(stream, d_cols, width, s.log_n, d_w, d_partial, d_res));
-            if (!download(host_res.data(), d_res, (size_t)width * 2 * sizeof(Fp4))) return false;
-            local->resize(width);
-            if (next) next->resize(width);
-            for (uint32_t c = 0; c < width; c++) {
-                (*local)[c] = host_res[2 * c] * scale;
-                if (next) (*next)[c] = host_res[2 * c + 1] * scale;
-            }
+            HIPCHK(launch_open_columns(stream, d_cols, width, s.log_n, d_w, d_partial, d_res + res_off));
+            pending.push_back({res_off, width, scale, local, next});
+            res_off += (size_t)width * 2;
             return true;
         };
         pf.chips.resize(cs.size());
+        std::vector<std::vector<Fp4>> quot_vals(2 * cs.size());
         for (size_t k = 0; k < cs.size(); k++) {
             ChipState &s = cs[k];
             ChipOpening &o = pf.chips[k];
@@ -617,11 +618,22 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
                 Fp4 y = zeta * inv(sc);
                 HIPCHK(launch_open_weights(stream, tabs, y, s.log_n, d_w));
                 Fp4 qs = (pow(y, s.n) - Fp::one()) * ninv;
-                std::vector<Fp4> vals;
-                if (!open_matrix(s.quot + (size_t)4 * c * s.n, 4, s, qs, &vals, nullptr)) return false;
-                for (int j = 0; j < 4; j++) o.quot[4 * c + j] = vals[j];
+                if (!open_matrix(s.quot + (size_t)4 * c * s.n, 4, s, qs, &quot_vals[2 * k + c], nullptr)) return false;
             }
         }
+        std::vector<Fp4> host_res(res_off);
+        if (!download(host_res.data(), d_res, res_off * sizeof(Fp4))) return false;
+        for (auto &pd : pending) {
+            pd.local->resize(pd.width);
+            if (pd.next) pd.next->resize(pd.width);
+            for (uint32_t c = 0; c < pd.width; c++) {
+                (*pd.local)[c] = host_res[pd.off + 2 * c] * pd.scale;
+                if (pd.next) (*pd.next)[c] = host_res[pd.off + 2 * c + 1] * pd.scale;
+            }
+        }
+        for (size_t k = 0; k < cs.size(); k++)
+            for (int c = 0; c < 2; c++)
+                for (int j = 0; j < 4; j++) pf.chips[k].quot[4 * c + j] = quot_vals[2 * k + c][j];
         for (auto &o : pf.chips) {
             for (auto *v : {&o.prep_l, &o.prep_n, &o.main_l, &o.main_n, &o.perm_l, &o.perm_n, &o.quot})
                 for (auto &x : *v) ch.observe(x);
@@ -650,7 +662,10 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
             max_cols_h = std::max(max_cols_h, cols_by_h[h].size());
         }
         std::vector<Fp4> apow = ext_powers(alpha_fri, max_cols_h + 1, true);
-        const Fp4 *d_apow = upload_vec(apow);
+        std::vector<double> apow_d(4 * apow.size());
+        for (size_t c = 0; c < apow.size(); c++)
+            for (int k = 0; k < 4; k++) apow_d[4 * c + k] = centred_canonical(apow[c].c[k]);
+        const double *d_apow = reinterpret_cast<const double *>(upload(apow_d.data(), apow_d.size() * sizeof(double)));
         if (!d_apow) return false;
         for (uint32_t h = 1; h <= hmax; h++) {
             auto &cols = cols_by_h[h];

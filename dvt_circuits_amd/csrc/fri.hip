@@ -79,19 +79,43 @@ hipError_t launch_prefix_sum_columns(hipStream_t st, uint32_t *d_cols, uint32_t 
 size_t prefix_sum_scratch_words(uint32_t ncols, size_t n) { return ncols * ((n + SCAN_BLOCK - 1) / SCAN_BLOCK); }
 
 // ------------------------------------------------------------------ K6: openings
-// w[i] = omega_N^i / (z - omega_N^i)
+// w[i] = omega_N^i / (z - omega_N^i)  (centred canonical words, not Montgomery form: only open_columns reads them)
 __global__ void __launch_bounds__(256) open_weights_kernel(Fp4 z, uint32_t log_n, Fp4 *w, NttTables tabs) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ((size_t)1 << log_n)) return;
     Fp x = root_pow24f(tabs, (uint32_t)i << (24 - log_n));
     Fp4 d = z - x;
-    store_ext(w + i, inv(d) * x);
+    // stored as centred canonical residues (two's-complement words in (-p/2, p/2]): the operand format of the FP64
+    // dot products of open_columns_kernel, which turns a word into a double with one conversion
+    Fp4 r = inv(d) * x;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t c = r.c[k].canonical();
+        r.c[k] = Fp::raw(c > P / 2 ? c - P : c);
+    }
+    store_ext(w + i, r);
 }
 hipError_t launch_open_weights(hipStream_t st, const NttTables &tabs, Fp4 z, uint32_t log_n, Fp4 *d_w) {
     size_t n = (size_t)1 << log_n;
     open_weights_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(z, log_n, d_w, tabs);
     return hipGetLastError();
 }
+
+// ---- exact dot products on the FP64 pipe ---------------------------------------------------------------------
+// sum_i w_i * v_i with field weights w and field words v, as the K6 / K7 kernels need it (F_p^4 weight x F_p value =
+// four such sums).  A Montgomery product costs three quarter-rate integer multiplies plus a reduction per term; here
+// w is a centred residue in a double (|w| < 2^30) and v is split into 16-bit halves, so that w * v_lo and w * v_hi are
+// exact (< 2^46) and an FMA accumulates them exactly: two full-rate operations per term, one reduction every 32 terms
+// (32 * 2^46 + 2^30 < 2^52).  The sum is lo + 2^16 * hi.  v may be a Montgomery word: the sum is then the Montgomery
+// word of the true dot product (the map is linear), which is what both kernels store.
+struct DotAcc {
+    double lo, hi;
+    __device__ __forceinline__ void add(double w, double vlo, double vhi) { lo = fma(w, vlo, lo); hi = fma(w, vhi, hi); }
+    __device__ __forceinline__ void reduce() { lo = p2f::red(lo); hi = p2f::red(hi); }
+    __device__ __forceinline__ Fp value() const { return Fp::raw(p2f::fix(p2f::red(p2f::mm(p2f::red(hi), 65536.0) + p2f::red(lo)))); }
+};
+// centred canonical residue of a Montgomery word, as a double
+__device__ __forceinline__ double centred_from_mont(uint32_t m) { return p2f::mm((double)m, p2f::MONT_RINV); }
 
 // partial[rb][col][2] : unscaled sums  sum_i col[i]*w[i]  and  sum_i col[i]*w[i-1]
 constexpr int OPEN_CT = 4;  // columns per thread
@@ -100,25 +124,47 @@ __global__ void __launch_bounds__(256) open_columns_kernel(const uint32_t *const
     __shared__ uint32_t red[256 * 4];
     const size_t n = (size_t)1 << log_n;
     const uint32_t c0 = blockIdx.y * OPEN_CT;
-    Fp4 acc_l[OPEN_CT], acc_n[OPEN_CT];
+    DotAcc acc_l[OPEN_CT][4], acc_n[OPEN_CT][4];
 #pragma unroll
-    for (int c = 0; c < OPEN_CT; c++) acc_l[c] = acc_n[c] = Fp4::zero();
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        Fp4 wl = load_ext(w + i), wn = load_ext(w + ((i + n - 1) & (n - 1)));
+    for (int c = 0; c < OPEN_CT; c++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc_l[c][k] = acc_n[c][k] = DotAcc{0.0, 0.0};
+    // software-pipelined over the rows of this thread: the words of the next row are in flight while the current one
+    // is accumulated (a thread walks its rows with a dependent load -> FMA chain otherwise)
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    Fp4 wl, wn;
+    uint32_t v[OPEN_CT];
+    auto fetch = [&](size_t row) {
+        wl = load_ext(w + row);
+        wn = load_ext(w + ((row + n - 1) & (n - 1)));
+#pragma unroll
+        for (int c = 0; c < OPEN_CT; c++) v[c] = c0 + c < ncols ? cols[c0 + c][row] : 0u;
+    };
+    if (i < n) fetch(i);
+    for (uint32_t it = 0; i < n; i += stride, it++) {
+        double dl[4], dn[4], vlo[OPEN_CT], vhi[OPEN_CT];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { dl[k] = (double)(int32_t)wl.c[k].v; dn[k] = (double)(int32_t)wn.c[k].v; }
+#pragma unroll
+        for (int c = 0; c < OPEN_CT; c++) { vlo[c] = (double)(v[c] & 0xffffu); vhi[c] = (double)(v[c] >> 16); }
+        if (i + stride < n) fetch(i + stride);
 #pragma unroll
         for (int c = 0; c < OPEN_CT; c++)
-            if (c0 + c < ncols) {
-                Fp v = Fp::raw(cols[c0 + c][i]);
-                acc_l[c] += wl * v;
-                acc_n[c] += wn * v;
-            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) { acc_l[c][k].add(dl[k], vlo[c], vhi[c]); acc_n[c][k].add(dn[k], vlo[c], vhi[c]); }
+        if ((it & 31) == 31) {
+#pragma unroll
+            for (int c = 0; c < OPEN_CT; c++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) { acc_l[c][k].reduce(); acc_n[c][k].reduce(); }
+        }
     }
     // block reduction, one (column, point) at a time
     for (int c = 0; c < OPEN_CT; c++)
         for (int pt = 0; pt < 2; pt++) {
-            const Fp4 &a = pt ? acc_n[c] : acc_l[c];
 #pragma unroll
-            for (int k = 0; k < 4; k++) red[k * 256 + threadIdx.x] = a.c[k].v;
+            for (int k = 0; k < 4; k++) red[k * 256 + threadIdx.x] = (pt ? acc_n[c][k] : acc_l[c][k]).value().v;
             __syncthreads();
             for (int off = 128; off > 0; off >>= 1) {
                 if ((int)threadIdx.x < off)
@@ -142,10 +188,10 @@ __global__ void open_reduce_kernel(const Fp4 *partial, uint32_t nrb, uint32_t nv
     for (uint32_t rb = 0; rb < nrb; rb++) acc += load_ext(partial + (size_t)rb * nvals + v);
     store_ext(out + v, acc);
 }
-uint32_t open_row_blocks(uint32_t log_n) {
+uint32_t open_row_blocks(uint32_t log_n) {  // <= OPEN_MAX_ROW_BLOCKS (kernels.h): callers size d_partial with it
     size_t n = (size_t)1 << log_n;
     size_t rb = (n + 255) / 256;
-    return (uint32_t)(rb > 64 ? 64 : rb);
+    return (uint32_t)(rb > OPEN_MAX_ROW_BLOCKS ? OPEN_MAX_ROW_BLOCKS : rb);
 }
 // d_out[col][2]; d_partial must hold open_row_blocks(log_n) * ncols * 2 ext elements
 hipError_t launch_open_columns(hipStream_t st, const uint32_t *const *d_cols, uint32_t ncols, uint32_t log_n, const Fp4 *d_w,
@@ -162,7 +208,7 @@ hipError_t launch_open_columns(hipStream_t st, const uint32_t *const *d_cols, ui
 struct ReducedArgs {
     const uint32_t *const *cols;  // LDE columns of this height: two-point columns first
     uint32_t n_two, n_all, log_m;
-    const Fp4 *alpha_pows;
+    const double *alpha_pows;     // [n_all][4]: alpha^c as centred canonical residues (exact doubles)
     Fp4 sz_all, sz_two;  // sum_c alpha^c p_c(zeta) over all columns / p_c(zeta*omega) over two-point columns
     Fp4 zeta, zeta_next, alpha_shift;  // alpha^{n_all}
     Fp4 *out;
@@ -172,20 +218,34 @@ __global__ void __launch_bounds__(256) reduced_opening_kernel(ReducedArgs a) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t m = (size_t)1 << a.log_m;
     if (i >= m) return;
-    Fp4 s = Fp4::zero();
-    uint32_t c = 0;
-    for (; c < a.n_two; c++) s += a.alpha_pows[c] * Fp::raw(a.cols[c][i]);
-    Fp4 s_two = s;
-    for (; c < a.n_all; c++) s += a.alpha_pows[c] * Fp::raw(a.cols[c][i]);
+    // s = sum_c alpha^c * col_c[i] in F_p^4: four exact FP64 dot products (DotAcc above); alpha^c is wave-uniform
+    DotAcc acc[4] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+    Fp4 s_two = Fp4::zero();
+    for (uint32_t c = 0; c < a.n_all; c++) {
+        if (c == a.n_two)
+#pragma unroll
+            for (int k = 0; k < 4; k++) s_two.c[k] = acc[k].value();
+        const uint32_t v = a.cols[c][i];
+        const double vlo = (double)(v & 0xffffu), vhi = (double)(v >> 16);
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[k].add(a.alpha_pows[4 * c + k], vlo, vhi);
+        if ((c & 31) == 31)
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[k].reduce();
+    }
+    Fp4 s;
+#pragma unroll
+    for (int k = 0; k < 4; k++) s.c[k] = acc[k].value();
+    if (a.n_two == a.n_all) s_two = s;
     Fp x = Fp::raw(a.tabs.sh_lo[1]) * root_pow24f(a.tabs, (uint32_t)i << (24 - a.log_m));
     Fp4 r = (s - a.sz_all) * inv(Fp4::from_base(x) - a.zeta);
     if (a.n_two) r += a.alpha_shift * ((s_two - a.sz_two) * inv(Fp4::from_base(x) - a.zeta_next));
     store_ext(a.out + i, r);
 }
 hipError_t launch_reduced_opening(hipStream_t st, const NttTables &tabs, const uint32_t *const *d_cols, uint32_t n_two,
-                                  uint32_t n_all, uint32_t log_m, const Fp4 *d_alpha_pows, Fp4 sz_all, Fp4 sz_two, Fp4 zeta,
+                                  uint32_t n_all, uint32_t log_m, const double *d_alpha_pows_f64, Fp4 sz_all, Fp4 sz_two, Fp4 zeta,
                                   Fp4 zeta_next, Fp4 alpha_shift, Fp4 *d_out) {
-    ReducedArgs a{d_cols, n_two, n_all, log_m, d_alpha_pows, sz_all, sz_two, zeta, zeta_next, alpha_shift, d_out, tabs};
+    ReducedArgs a{d_cols, n_two, n_all, log_m, d_alpha_pows_f64, sz_all, sz_two, zeta, zeta_next, alpha_shift, d_out, tabs};
     size_t m = (size_t)1 << log_m;
     reduced_opening_kernel<<<(unsigned)((m + 255) / 256), 256, 0, st>>>(a);
     return hipGetLastError();

@@ -55,11 +55,13 @@ hipError_t launch_poseidon2_permute(hipStream_t st, uint32_t *d_states, size_t n
 hipError_t launch_prefix_sum_columns(hipStream_t st, uint32_t *d_cols, uint32_t ncols, size_t n, uint32_t *d_scratch);
 size_t prefix_sum_scratch_words(uint32_t ncols, size_t n);
 hipError_t launch_open_weights(hipStream_t st, const NttTables &tabs, Fp4 z, uint32_t log_n, Fp4 *d_w);
+constexpr uint32_t OPEN_MAX_ROW_BLOCKS = 256;
 uint32_t open_row_blocks(uint32_t log_n);
 hipError_t launch_open_columns(hipStream_t st, const uint32_t *const *d_cols, uint32_t ncols, uint32_t log_n, const Fp4 *d_w,
                                Fp4 *d_partial, Fp4 *d_out);
+// d_alpha_pows_f64: [n_all][4] doubles, alpha^c as centred canonical residues (see centred_canonical in bb.cuh)
 hipError_t launch_reduced_opening(hipStream_t st, const NttTables &tabs, const uint32_t *const *d_cols, uint32_t n_two,
-                                  uint32_t n_all, uint32_t log_m, const Fp4 *d_alpha_pows, Fp4 sz_all, Fp4 sz_two, Fp4 zeta,
+                                  uint32_t n_all, uint32_t log_m, const double *d_alpha_pows_f64, Fp4 sz_all, Fp4 sz_two, Fp4 zeta,
                                   Fp4 zeta_next, Fp4 alpha_shift, Fp4 *d_out);
 hipError_t launch_fri_fold(hipStream_t st, const NttTables &tabs, const Fp4 *d_v, Fp4 *d_out, const Fp4 *d_ro, Fp4 beta,
                            uint32_t log_m);
