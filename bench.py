@@ -97,8 +97,15 @@ def main():
 
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    # DVT_BENCH_REHEARSAL=1: rehearse the N > 1 control flow on a ONE-GPU box (every rank proves on cuda:0, collectives over
+    # gloo on host tensors).  Numbers from such a run mean nothing; it exists so that the multi-rank path is exercised before
+    # the driver's 8-GPU run.
+    rehearsal = os.environ.get("DVT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
-    ranks = Ranks(backend="nccl", device=torch.device("cuda", local))   # nccl == RCCL on ROCm
+    coll = torch.device("cpu") if rehearsal else torch.device("cuda", local)     # where collective operands live
+    ranks = Ranks(backend="gloo" if rehearsal else "nccl", device=coll)   # nccl == RCCL on ROCm
     rank, world = ranks.rank, ranks.world
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
@@ -126,9 +133,9 @@ def main():
 
         if world == 1:
             return np.stack(local_headers)
-        h = torch.zeros((n_shards, 15), dtype=torch.int64, device="cuda")
+        h = torch.zeros((n_shards, 15), dtype=torch.int64, device=coll)
         for i, hd in zip(mine, local_headers):
-            h[i] = torch.from_numpy(hd.astype(np.int64)).cuda()
+            h[i] = torch.from_numpy(hd.astype(np.int64)).to(coll)
         ranks.dist.all_reduce(h)   # disjoint rows: sum == gather
         return h.cpu().numpy().astype(np.uint32)
 
@@ -146,14 +153,14 @@ def main():
     else:
         import numpy as np
 
-        lens = torch.zeros(n_shards, dtype=torch.int64, device="cuda")
+        lens = torch.zeros(n_shards, dtype=torch.int64, device=coll)
         for i, sp in zip(mine, shard_proofs):
             lens[i] = len(sp)
         ranks.dist.all_reduce(lens)
         mx = int(lens.max().item())
-        buf = torch.zeros((n_shards, mx), dtype=torch.uint8, device="cuda")
+        buf = torch.zeros((n_shards, mx), dtype=torch.uint8, device=coll)
         for i, sp in zip(mine, shard_proofs):
-            buf[i, : len(sp)] = torch.frombuffer(bytearray(sp), dtype=torch.uint8).cuda()
+            buf[i, : len(sp)] = torch.frombuffer(bytearray(sp), dtype=torch.uint8).to(coll)
         ranks.dist.all_reduce(buf)
         if rank == 0:
             allp = [bytes(buf[i, : int(lens[i].item())].cpu().numpy()) for i in range(n_shards)]
