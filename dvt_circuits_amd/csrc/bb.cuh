@@ -81,7 +81,18 @@ DVT_HD Fp pow(Fp a, uint64_t e) {
     while (e) { if (e & 1) r = r * a; a = a * a; e >>= 1; }
     return r;
 }
-DVT_HD Fp inv(Fp a) { return pow(a, P - 2); }
+// a^(p-2), p - 2 = 0x77FFFFFF = 111 0 then 27 ones: a^7, one squaring, then nine times (three squarings, times a^7):
+// 30 squarings + 11 products instead of the 58 of plain square-and-multiply
+DVT_HD Fp inv(Fp a) {
+    const Fp a2 = a * a, a3 = a2 * a, a7 = a3 * a3 * a;
+    Fp r = a7 * a7;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        r = r * r; r = r * r; r = r * r;
+        r = r * a7;
+    }
+    return r;
+}
 // primitive 2^k-th root of unity 31^((p-1)/2^k); host-side helper (slow)
 inline Fp two_adic_generator(unsigned k) { return pow(Fp::from_canonical(31), (uint64_t)(P - 1) >> k); }
 constexpr uint32_t COSET_SHIFT = 31;

@@ -43,7 +43,8 @@ hipError_t launch_merkle_leaves(hipStream_t st, const uint32_t *const *d_cols, u
 hipError_t launch_merkle_level(hipStream_t st, const uint32_t *d_prev, const uint32_t *const *d_cols, uint32_t ncols,
                                uint32_t log_len, uint32_t *d_out);
 // every level below a layer of 2^log_start <= 2^MERKLE_TOP_LOG nodes, down to the root, in one launch
-constexpr uint32_t MERKLE_TOP_LOG = 6;   // one wave per level: below this the levels are latency-, not throughput-bound
+constexpr uint32_t MERKLE_TOP_LOG = 6;   // below this the levels share one single-workgroup launch (16 lanes per node)
+constexpr uint32_t MERKLE_COOP_LOG = 13; // levels of at most 2^13 nodes run one node per 16 lanes (latency-, not throughput-bound)
 struct MerkleTopInject {  // per level lh (nodes = 2^lh): columns injected at that level
     const uint32_t *const *cols[MERKLE_TOP_LOG + 1] = {};
     uint32_t ncols[MERKLE_TOP_LOG + 1] = {};

@@ -90,28 +90,51 @@ __global__ void __launch_bounds__(256) merkle_level_kernel(const uint32_t *prev,
     store_digest(out, i, s);
 }
 
+// ---- latency-bound levels: one node per 16 lanes (p2f::coop_permute) ---------------------------------------------------
+// node i of a level of `len` nodes = compress(child i, child i + len) [+ injected matrices]; lane e of the node's row holds
+// state element e.  Blocks are whole rows; rows beyond `len` run along (DPP needs the full row) and store nothing.
+__device__ __forceinline__ void coop_node(const uint32_t *prev, const uint32_t *const *cols, uint32_t ncols, size_t i, size_t len,
+                                          bool live, uint32_t e, const p2f::CoopConsts &k, uint32_t *out) {
+    const size_t src = e < 8 ? i * 8 + e : (i + len) * 8 + (e - 8);
+    double s = p2f::from_mont(live ? prev[src] : 0u);
+    s = p2f::coop_permute(s, k);
+    if (ncols) {
+        // sponge over row i of the injected columns (rate 8 = lanes 0..7, capacity in lanes 8..15), then one more
+        // compression of (node, sponge digest)
+        double h = 0.0;
+        for (uint32_t g = 0; g < ncols; g += 8) {
+            if (e < 8 && g + e < ncols) h = p2f::from_mont(live ? cols[g + e][i] : 0u);
+            h = p2f::coop_permute(h, k);
+        }
+        // lanes 8..15 take the digest words 0..7 of the sponge (row rotation by 8), lanes 0..7 keep the node
+        const double hs = p2f::dpp_mov<p2f::DPP_ROW_ROR + 8>(h);
+        s = e < 8 ? s : hs;
+        s = p2f::coop_permute(s, k);
+    }
+    if (live && e < 8) out[i * 8 + e] = p2f::to_mont(s);
+}
+
+__global__ void __launch_bounds__(256) merkle_level_coop_kernel(const uint32_t *prev, const uint32_t *const *cols, uint32_t ncols,
+                                                               size_t len, uint32_t *out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t e = threadIdx.x & 15;
+    const p2f::CoopConsts k = p2f::coop_consts(e);
+    coop_node(prev, cols, ncols, t >> 4, len, (t >> 4) < len, e, k, out);
+}
+
 // All levels from a layer of 2^log_start nodes (log_start <= MERKLE_TOP_LOG) down to the root in ONE
 // single-workgroup launch: the upper levels are launch-latency bound (a proof has ~25 trees x ~11 of
 // them), so they share a launch and synchronise with __syncthreads().  Every node is written once and
 // read once afterwards by the same workgroup, so no cross-CU visibility is involved.
 __global__ void __launch_bounds__(1024) merkle_top_kernel(uint32_t *layer, uint32_t log_start, MerkleTopInject inj) {
+    const uint32_t e = threadIdx.x & 15, slot = threadIdx.x >> 4, slots = blockDim.x >> 4;
+    const p2f::CoopConsts k = p2f::coop_consts(e);
     uint32_t *prev = layer;
     for (uint32_t lh = log_start; lh-- > 0;) {
         const size_t len = (size_t)1 << lh;
         uint32_t *cur = prev + ((size_t)16 << lh);
-        for (size_t i = threadIdx.x; i < len; i += blockDim.x) {
-            double s[16];
-            load_children(prev, i, len, s);
-            p2f::permute(s);
-            if (inj.ncols[lh]) {
-                double h[16];
-                hash_row(inj.cols[lh], inj.ncols[lh], i, h);
-#pragma unroll
-                for (int k = 0; k < 8; k++) s[8 + k] = h[k];
-                p2f::permute(s);
-            }
-            store_digest(cur, i, s);
-        }
+        for (size_t base = 0; base < len; base += slots)       // uniform trip count: every row takes part in every pass
+            coop_node(prev, inj.cols[lh], inj.ncols[lh], base + slot, len, base + slot < len, e, k, cur);
         __threadfence_block();
         __syncthreads();
         prev = cur;
@@ -121,7 +144,10 @@ __global__ void __launch_bounds__(1024) merkle_top_kernel(uint32_t *layer, uint3
 hipError_t launch_merkle_top(hipStream_t st, uint32_t *d_layer, uint32_t log_start, const MerkleTopInject &inj) {
     if (log_start == 0) return hipSuccess;
     if (log_start > MERKLE_TOP_LOG) return hipErrorInvalidValue;
-    unsigned threads = log_start >= 11 ? 1024 : (log_start <= 6 ? 64 : 1u << (log_start - 1));
+    // 16 lanes per node; the first level below the start layer has 2^(log_start-1) nodes
+    unsigned threads = 16u << (log_start - 1);
+    if (threads < 64) threads = 64;
+    if (threads > 1024) threads = 1024;
     merkle_top_kernel<<<1, threads, 0, st>>>(d_layer, log_start, inj);
     return hipGetLastError();
 }
@@ -148,6 +174,11 @@ hipError_t launch_merkle_leaves(hipStream_t st, const uint32_t *const *d_cols, u
 hipError_t launch_merkle_level(hipStream_t st, const uint32_t *d_prev, const uint32_t *const *d_cols, uint32_t ncols,
                                uint32_t log_len, uint32_t *d_out) {
     size_t len = (size_t)1 << log_len;
+    if (log_len <= MERKLE_COOP_LOG) {  // too few nodes to fill the GPU with one thread each: 16 lanes per node
+        unsigned blocks = (unsigned)((len * 16 + 255) / 256);
+        merkle_level_coop_kernel<<<blocks, 256, 0, st>>>(d_prev, d_cols, ncols, len, d_out);
+        return hipGetLastError();
+    }
     unsigned blocks = (unsigned)((len + 255) / 256);
     merkle_level_kernel<<<blocks, 256, 0, st>>>(d_prev, d_cols, ncols, len, d_out);
     return hipGetLastError();

@@ -33,6 +33,7 @@ namespace p2f {
 #define DVT_DEV DVT_HD
 DVT_F64_TABLE double RC_EXT[128] = DVT_P2_RC_EXT_F64_INIT;
 DVT_F64_TABLE double RC_INT[13] = DVT_P2_RC_INT_F64_INIT;
+DVT_F64_TABLE double DIAG[16] = DVT_P2_DIAG_F64_INIT;
 
 constexpr double PD = 2013265921.0;
 constexpr double PINV = 1.0 / 2013265921.0;
@@ -139,6 +140,68 @@ DVT_DEV void permute(double s[16]) {
 #pragma unroll
     for (int i = 0; i < 16; i++) s[i] = red(s[i]);
 }
+
+#if defined(__HIPCC__)
+// ---- the same permutation, one state per 16 LANES (lane e of a DPP row holds state element e) ---------------------
+// A thread that owns a whole state runs ~5 600 FP64 operations back to back: ~9 us however few states there are, which
+// is what the small Merkle levels and every tree top cost per level.  Spread over a DPP row the S-boxes of a round run
+// in parallel and the linear layers become quad permutes / row rotations (v_mov_b32_dpp, no LDS): ~1 000 dependent
+// operations per permutation.  Used where there are too few states to fill the machine anyway (merkle.hip).
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_QUAD_NEXT = 0x39;   // quad_perm [1,2,3,0]: lane k reads lane k+1 of its quad
+constexpr int DPP_QUAD_XOR1 = 0xB1;   // quad_perm [1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;   // quad_perm [2,3,0,1]
+constexpr int DPP_ROW_ROR = 0x120;    // + n: rotate the 16-lane row by n
+
+struct CoopConsts {
+    double rc[8];   // external round constants of this lane's element
+    double diag;    // internal diagonal entry of this lane's element (centred residue)
+    bool lane0;
+};
+__device__ __forceinline__ CoopConsts coop_consts(uint32_t e) {
+    CoopConsts k;
+#pragma unroll
+    for (int r = 0; r < 8; r++) k.rc[r] = RC_EXT[16 * r + e];
+    k.diag = DIAG[e];
+    k.lane0 = e == 0;
+    return k;
+}
+// max |s| = B -> <= 35 B (as external_layer)
+__device__ __forceinline__ double coop_external_layer(double x) {
+    const double x1 = dpp_mov<DPP_QUAD_NEXT>(x);
+    double t = x + dpp_mov<DPP_QUAD_XOR1>(x);
+    t = t + dpp_mov<DPP_QUAD_XOR2>(t);
+    const double y = fma(2.0, x1, t + x);
+    double a = y + dpp_mov<DPP_ROW_ROR + 8>(y);
+    a = a + dpp_mov<DPP_ROW_ROR + 4>(a);
+    return y + a;
+}
+// in: |s| < 2^32; out: |s| < 0.51 p (every lane of the row must be active)
+__device__ __forceinline__ double coop_permute(double s, const CoopConsts &k) {
+    s = coop_external_layer(s);
+#pragma unroll
+    for (int r = 0; r < 4; r++) s = coop_external_layer(sbox(s + k.rc[r]));
+    s = red(s);
+#pragma unroll
+    for (int r = 0; r < 13; r++) {
+        const double x = sbox(s + RC_INT[r]);
+        s = k.lane0 ? x : s;
+        double t = s + dpp_mov<DPP_ROW_ROR + 8>(s);
+        t = t + dpp_mov<DPP_ROW_ROR + 4>(t);
+        t = t + dpp_mov<DPP_ROW_ROR + 2>(t);
+        t = t + dpp_mov<DPP_ROW_ROR + 1>(t);
+        s = red(t + mm(s, k.diag));          // every entry stays reduced: |sum| <= 16 * 0.51 p
+    }
+#pragma unroll
+    for (int r = 4; r < 8; r++) s = coop_external_layer(sbox(s + k.rc[r]));
+    return red(s);
+}
+#endif
 
 }  // namespace p2f
 }  // namespace dvt
