@@ -748,6 +748,27 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
     pf.queries.assign(nq, QueryProof());
     const uint32_t *trees_dev[4] = {pk.d_prep_digests, d_main_tree, d_perm_tree, d_quot_tree};
     const uint32_t trees_h[4] = {pk.prep_log_h, hmax, perm_hmax, hmax};
+    // every gather writes into one device buffer; ONE download afterwards (50 small synchronous copies cost ~2 ms)
+    struct Slot { size_t rows_at = 0, paths_at = 0; uint32_t ncols = 0; };
+    Slot tree_slot[4];
+    std::vector<Slot> layer_slot(layers.size());
+    size_t q_words = 0;
+    uint32_t tree_ncols[4] = {0, 0, 0, 0};
+    for (int t = 0; t < 4; t++) {
+        for (auto &tmx : tree_mats[t]) tree_ncols[t] += tmx.width;
+        if (tree_mats[t].empty()) continue;
+        tree_slot[t].ncols = tree_ncols[t];
+        tree_slot[t].rows_at = q_words; q_words += (size_t)nq * tree_ncols[t];
+        q_words = (q_words + 3) & ~(size_t)3;
+        tree_slot[t].paths_at = q_words; q_words += (size_t)nq * trees_h[t] * 8 + 8;
+    }
+    for (size_t l = 0; l < layers.size(); l++) {
+        q_words = (q_words + 3) & ~(size_t)3;  // 16-byte aligned: gather_siblings stores uint4
+        layer_slot[l].rows_at = q_words; q_words += (size_t)nq * 4;
+        layer_slot[l].paths_at = q_words; q_words += (size_t)nq * (layers[l].log_m - 1) * 8 + 8;
+    }
+    uint32_t *d_q;
+    ALLOC(d_q, uint32_t, q_words);
     for (int t = 0; t < 4; t++) {
         if (tree_mats[t].empty()) continue;
         std::vector<uint64_t> ptrs;
@@ -760,15 +781,20 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
         auto d_cols = reinterpret_cast<const uint32_t *const *>(upload(ptrs.data(), ptrs.size() * 8));
         const uint32_t *d_lh = upload_vec(lhs);
         if (!d_cols || !d_lh) return false;
-        uint32_t ncols = (uint32_t)ptrs.size();
-        uint32_t *d_rows, *d_paths;
-        ALLOC(d_rows, uint32_t, (size_t)nq * ncols);
-        ALLOC(d_paths, uint32_t, (size_t)nq * trees_h[t] * 8 + 8);
-        HIPCHK(launch_gather_rows(stream, d_cols, d_lh, ncols, d_idx, nq, d_rows));
-        HIPCHK(launch_gather_paths(stream, trees_dev[t], trees_h[t], d_idx, nq, d_paths));
-        std::vector<uint32_t> rows((size_t)nq * ncols), paths((size_t)nq * trees_h[t] * 8);
-        if (!download(rows.data(), d_rows, rows.size() * 4)) return false;
-        if (!paths.empty() && !download(paths.data(), d_paths, paths.size() * 4)) return false;
+        HIPCHK(launch_gather_rows(stream, d_cols, d_lh, tree_ncols[t], d_idx, nq, d_q + tree_slot[t].rows_at));
+        HIPCHK(launch_gather_paths(stream, trees_dev[t], trees_h[t], d_idx, nq, d_q + tree_slot[t].paths_at));
+    }
+    for (size_t l = 0; l < layers.size(); l++) {
+        auto &L = layers[l];
+        HIPCHK(launch_gather_siblings(stream, L.v, L.log_m, d_idx, nq, reinterpret_cast<Fp4 *>(d_q + layer_slot[l].rows_at)));
+        HIPCHK(launch_gather_paths(stream, L.tree, L.log_m - 1, d_idx, nq, d_q + layer_slot[l].paths_at));
+    }
+    std::vector<uint32_t> hq(q_words);
+    if (!download(hq.data(), d_q, q_words * 4)) return false;
+    for (int t = 0; t < 4; t++) {
+        if (tree_mats[t].empty()) continue;
+        const uint32_t *rows = hq.data() + tree_slot[t].rows_at, *paths = hq.data() + tree_slot[t].paths_at;
+        const uint32_t ncols = tree_ncols[t];
         for (uint32_t q = 0; q < nq; q++) {
             TreeOpening &to = pf.queries[q].trees[t];
             size_t at = (size_t)q * ncols;
@@ -782,17 +808,9 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
             for (uint32_t l = 0; l < trees_h[t]; l++) to.path[l] = digest_from_words(&paths[((size_t)q * trees_h[t] + l) * 8]);
         }
     }
-    for (auto &L : layers) {
-        Fp4 *d_sib;
-        uint32_t *d_paths;
-        const uint32_t th = L.log_m - 1;
-        ALLOC(d_sib, Fp4, nq);
-        ALLOC(d_paths, uint32_t, (size_t)nq * th * 8 + 8);
-        HIPCHK(launch_gather_siblings(stream, L.v, L.log_m, d_idx, nq, d_sib));
-        HIPCHK(launch_gather_paths(stream, L.tree, th, d_idx, nq, d_paths));
-        std::vector<uint32_t> sib((size_t)nq * 4), paths((size_t)nq * th * 8);
-        if (!download(sib.data(), d_sib, sib.size() * 4)) return false;
-        if (!paths.empty() && !download(paths.data(), d_paths, paths.size() * 4)) return false;
+    for (size_t li = 0; li < layers.size(); li++) {
+        const uint32_t th = layers[li].log_m - 1;
+        const uint32_t *sib = hq.data() + layer_slot[li].rows_at, *paths = hq.data() + layer_slot[li].paths_at;
         for (uint32_t q = 0; q < nq; q++) {
             FriLayerOpening lo;
             for (int k = 0; k < 4; k++) lo.sibling.c[k] = Fp::raw(sib[(size_t)q * 4 + k]);

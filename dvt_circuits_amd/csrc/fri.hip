@@ -181,12 +181,17 @@ __global__ void __launch_bounds__(256) open_columns_kernel(const uint32_t *const
             __syncthreads();
         }
 }
-__global__ void open_reduce_kernel(const Fp4 *partial, uint32_t nrb, uint32_t nvals, Fp4 *out) {
-    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= nvals) return;
+// 16 lanes per value: lane j sums the row blocks j, j + 16, ..., then a 4-step butterfly over the 16 lanes
+__global__ void __launch_bounds__(256) open_reduce_kernel(const Fp4 *partial, uint32_t nrb, uint32_t nvals, Fp4 *out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, v = t >> 4, j = t & 15;
     Fp4 acc = Fp4::zero();
-    for (uint32_t rb = 0; rb < nrb; rb++) acc += load_ext(partial + (size_t)rb * nvals + v);
-    store_ext(out + v, acc);
+    if (v < nvals)
+        for (uint32_t rb = j; rb < nrb; rb += 16) acc += load_ext(partial + (size_t)rb * nvals + v);
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc.c[k] = acc.c[k] + Fp::raw(__shfl_xor(acc.c[k].v, off, 16));
+    if (v < nvals && j == 0) store_ext(out + v, acc);
 }
 uint32_t open_row_blocks(uint32_t log_n) {  // <= OPEN_MAX_ROW_BLOCKS (kernels.h): callers size d_partial with it
     size_t n = (size_t)1 << log_n;
@@ -200,7 +205,7 @@ hipError_t launch_open_columns(hipStream_t st, const uint32_t *const *d_cols, ui
     uint32_t rb = open_row_blocks(log_n);
     dim3 grid(rb, (ncols + OPEN_CT - 1) / OPEN_CT);
     open_columns_kernel<<<grid, 256, 0, st>>>(d_cols, ncols, log_n, d_w, d_partial);
-    open_reduce_kernel<<<(ncols * 2 + 255) / 256, 256, 0, st>>>(d_partial, rb, ncols * 2, d_out);
+    open_reduce_kernel<<<(ncols * 2 * 16 + 255) / 256, 256, 0, st>>>(d_partial, rb, ncols * 2, d_out);
     return hipGetLastError();
 }
 
