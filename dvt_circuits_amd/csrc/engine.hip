@@ -500,6 +500,15 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
     std::vector<Fp4> beta_pows = ext_powers(beta, max_arity, false);
     const Fp4 *d_beta = upload_vec(beta_pows);
     if (!d_beta) return false;
+    // the same powers as centred doubles: operands of the exact FP64 dot products of K4 / K5 (f64dot.cuh)
+    auto upload_centred = [&](const std::vector<Fp4> &v) -> const double * {
+        std::vector<double> d(4 * v.size());
+        for (size_t i = 0; i < v.size(); i++)
+            for (int k = 0; k < 4; k++) d[4 * i + k] = centred_canonical(v[i].c[k]);
+        return reinterpret_cast<const double *>(upload(d.data(), d.size() * sizeof(double)));
+    };
+    const double *d_beta_f64 = upload_centred(beta_pows);
+    if (!d_beta_f64) return false;
     mats.clear();
     uint32_t perm_hmax = 0;
     for (auto &s : cs) {
@@ -507,7 +516,7 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
         const size_t bw = 4 * (size_t)s.d->perm_ext_w;
         ALLOC(s.perm, uint32_t, bw * s.n);
         ALLOC(s.perm_lde, uint32_t, bw * 2 * s.n);
-        PermArgs pa{s.main, s.prep, d_pub, s.perm, d_beta, perm_alpha, s.log_n};
+        PermArgs pa{s.main, s.prep, d_pub, s.perm, d_beta, d_beta_f64, perm_alpha, s.log_n};
         HIPCHK(s.d->launch_perm(stream, pa));
         uint32_t *phi = s.perm + (bw - 4) * s.n;
         uint32_t *scan_scratch;
@@ -538,7 +547,8 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
     Fp4 alpha = ch.sample_ext();
     std::vector<Fp4> alpha_pows = ext_powers(alpha, max_folded, true);
     const Fp4 *d_alpha = upload_vec(alpha_pows);
-    if (!d_alpha) return false;
+    const double *d_alpha_f64 = upload_centred(alpha_pows);
+    if (!d_alpha || !d_alpha_f64) return false;
     mats.clear();
     const Fp g = Fp::from_canonical(COSET_SHIFT);
     for (auto &s : cs) {
@@ -546,7 +556,8 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
         ALLOC(s.quot_lde, uint32_t, 16 * s.n);
         QuotientArgs qa;
         qa.main_lde = s.main_lde; qa.prep_lde = s.prep_lde; qa.perm_lde = s.perm_lde; qa.pub = d_pub; qa.out = s.quot;
-        qa.alpha_pows = d_alpha; qa.beta_pows = d_beta; qa.perm_alpha = perm_alpha; qa.cumsum = s.cumsum;
+        qa.alpha_pows = d_alpha; qa.beta_pows = d_beta; qa.alpha_d = d_alpha_f64; qa.beta_d = d_beta_f64;
+        qa.perm_alpha = perm_alpha; qa.cumsum = s.cumsum;
         Fp gn = pow(g, s.n);
         qa.z_even = gn - Fp::one();
         qa.z_odd = -gn - Fp::one();

@@ -5,6 +5,7 @@
 // a layer's Merkle leaf i is the pair itself.
 #include "kernels.h"
 #include "poseidon2_f64.cuh"
+#include "f64dot.cuh"
 
 namespace dvt {
 
@@ -100,22 +101,6 @@ hipError_t launch_open_weights(hipStream_t st, const NttTables &tabs, Fp4 z, uin
     open_weights_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(z, log_n, d_w, tabs);
     return hipGetLastError();
 }
-
-// ---- exact dot products on the FP64 pipe ---------------------------------------------------------------------
-// sum_i w_i * v_i with field weights w and field words v, as the K6 / K7 kernels need it (F_p^4 weight x F_p value =
-// four such sums).  A Montgomery product costs three quarter-rate integer multiplies plus a reduction per term; here
-// w is a centred residue in a double (|w| < 2^30) and v is split into 16-bit halves, so that w * v_lo and w * v_hi are
-// exact (< 2^46) and an FMA accumulates them exactly: two full-rate operations per term, one reduction every 32 terms
-// (32 * 2^46 + 2^30 < 2^52).  The sum is lo + 2^16 * hi.  v may be a Montgomery word: the sum is then the Montgomery
-// word of the true dot product (the map is linear), which is what both kernels store.
-struct DotAcc {
-    double lo, hi;
-    __device__ __forceinline__ void add(double w, double vlo, double vhi) { lo = fma(w, vlo, lo); hi = fma(w, vhi, hi); }
-    __device__ __forceinline__ void reduce() { lo = p2f::red(lo); hi = p2f::red(hi); }
-    __device__ __forceinline__ Fp value() const { return Fp::raw(p2f::fix(p2f::red(p2f::mm(p2f::red(hi), 65536.0) + p2f::red(lo)))); }
-};
-// centred canonical residue of a Montgomery word, as a double
-__device__ __forceinline__ double centred_from_mont(uint32_t m) { return p2f::mm((double)m, p2f::MONT_RINV); }
 
 // partial[rb][col][2] : unscaled sums  sum_i col[i]*w[i]  and  sum_i col[i]*w[i-1]
 constexpr int OPEN_CT = 4;  // columns per thread

@@ -17,6 +17,7 @@
 // (stock SP1 keeps this in sp1-stark, absent.)
 #pragma once
 #include "bb.cuh"
+#include "f64dot.cuh"
 #include "kernels.h"
 
 namespace dvt {
@@ -43,6 +44,11 @@ struct ConstraintFolder {
     const Access &ax;
     const Fp4 *alpha_pows;  // [N_FOLDED]
     const Fp4 *beta_pows;   // beta^1 .. beta^MAX_ARITY at [0..]
+    // T = Fp (the gfx950 quotient kernel) only: the same powers as centred doubles [..][4].  Products of a (wave-uniform)
+    // power with a base-field value are then accumulated exactly on the FP64 pipe (f64dot.cuh) instead of as four
+    // Montgomery products each; F_p^4 x F_p^4 products stay in Montgomery arithmetic.
+    const double *alpha_d = nullptr, *beta_d = nullptr;
+    DotAcc4 acc_d;
     Fp4 perm_alpha;
     T sel_first, sel_last, sel_trans;
     Fp4 cumsum;
@@ -60,8 +66,31 @@ struct ConstraintFolder {
     DVT_HD T prep(int c, int r) const { return ax.prep(c, r); }
     DVT_HD T pub(int k) const { return ax.pub(k); }
 
+    static constexpr bool BASE = sizeof(T) == sizeof(Fp);
     DVT_HD void fold(int idx, const Fp4 &v) { acc += alpha_pows[idx] * v; }
-    DVT_HD void fold_t(int idx, const T &v) { acc += alpha_pows[idx] * v; }
+    DVT_HD void fold_t(int idx, const T &v) {
+        if constexpr (BASE) {
+            acc_d.add(alpha_d + 4 * idx, v);
+            if ((idx & 31) == 31) acc_d.reduce();   // idx is a literal in the generated code: resolved at compile time
+        } else {
+            acc += alpha_pows[idx] * v;
+        }
+    }
+    // d = alpha_p + bus + sum_k beta^(k+1) v_k
+    DVT_HD Fp4 denominator(int bus, const T *vals, int n) const {
+        Fp4 d = perm_alpha + Fp::from_canonical((uint32_t)bus);
+        if constexpr (BASE) {
+            DotAcc4 s;
+            for (int k = 0; k < n; k++) {
+                s.add(beta_d + 4 * k, vals[k]);
+                if ((k & 31) == 31) s.reduce();
+            }
+            d += s.value();
+        } else {
+            for (int k = 0; k < n; k++) d += beta_pows[k] * vals[k];
+        }
+        return d;
+    }
 
     DVT_HD void constraint(int idx, int when, const T &v) {
         if (when == WHEN_ALL) fold_t(idx, v);
@@ -71,8 +100,7 @@ struct ConstraintFolder {
     }
 
     DVT_HD void interaction(int j, int bus, int sign, int /*scope*/, const T &mult, const T *vals, int n) {
-        Fp4 d = perm_alpha + Fp::from_canonical((uint32_t)bus);
-        for (int k = 0; k < n; k++) d += beta_pows[k] * vals[k];
+        Fp4 d = denominator(bus, vals, n);
         T m = sign > 0 ? mult : -mult;
         if ((j & 1) == 0) {
             pend_m = m;
@@ -105,6 +133,7 @@ struct ConstraintFolder {
         Air::constraints(*this);
         Air::interactions(*this);
         finish_logup();
+        if constexpr (BASE) acc += acc_d.value();
         return acc;
     }
 };
@@ -117,6 +146,7 @@ struct PermArgs {
     const uint32_t *pub;   // device public values (Montgomery)
     uint32_t *perm;        // [4*EXT_W][N] out
     const Fp4 *beta_pows;  // device
+    const double *beta_d;  // the same powers as centred doubles [..][4] (f64dot.cuh)
     Fp4 perm_alpha;
     uint32_t log_n;
 };
@@ -137,9 +167,16 @@ struct PermRowCtx {
         for (int k = 0; k < 4; k++) a.perm[((size_t)(4 * extcol + k)) * n + row] = v.c[k].v;
     }
     __device__ void interaction(int j, int bus, int sign, int /*scope*/, const T &mult, const T *vals, int nv) {
-        Fp4 d = a.perm_alpha + Fp::from_canonical((uint32_t)bus);
-        for (int k = 0; k < nv; k++) d += a.beta_pows[k] * vals[k];
-        Fp4 term = mult.is_zero() ? Fp4::zero() : inv(d) * (sign > 0 ? mult : -mult);
+        Fp4 term = Fp4::zero();
+        if (!mult.is_zero()) {   // most interactions of a row are switched off by their selector
+            DotAcc4 s;
+            for (int k = 0; k < nv; k++) {
+                s.add(a.beta_d + 4 * k, vals[k]);
+                if ((k & 31) == 31) s.reduce();
+            }
+            Fp4 d = a.perm_alpha + Fp::from_canonical((uint32_t)bus) + s.value();
+            term = inv(d) * (sign > 0 ? mult : -mult);
+        }
         if ((j & 1) == 0) batch = term; else batch += term;
         if ((j & 1) || j == Air::N_INTERACTIONS - 1) {
             store_ext(j >> 1, batch);
@@ -166,6 +203,7 @@ struct QuotientArgs {
     uint32_t *out;             // two chunks: [2][4][N]  (even rows, odd rows)
     const Fp4 *alpha_pows;
     const Fp4 *beta_pows;
+    const double *alpha_d, *beta_d;   // centred doubles [..][4]
     Fp4 perm_alpha, cumsum;
     Fp zinv_even, zinv_odd;    // 1 / Z_H(x) on even / odd LDE rows
     Fp z_even, z_odd;          // Z_H(x) itself
@@ -198,6 +236,8 @@ __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
     ConstraintFolder<Air, Fp, QuotAccess> f(ax);
     f.alpha_pows = a.alpha_pows;
     f.beta_pows = a.beta_pows;
+    f.alpha_d = a.alpha_d;
+    f.beta_d = a.beta_d;
     f.perm_alpha = a.perm_alpha;
     f.cumsum = a.cumsum;
     // x = g * w_{2N}^i
