@@ -558,6 +558,7 @@ static int shard_prove(dvt_prover *p, const dvt_pk *pk, dvt_job *j, size_t i, co
     j->shards[i].traces_valid = false;
     if (!ok) return fail(p, DVT_ERR_DEVICE, "%s", p->eng.err.c_str());
     WordWriter w;
+    w.w.reserve((size_t)1 << 20);  // a shard proof is about 2.4 MB at 100 queries
     write_shard_proof(w, sp);
     *words = std::move(w.w);
     return DVT_OK;

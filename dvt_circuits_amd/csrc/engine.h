@@ -151,6 +151,8 @@ class Engine {
 
   private:
     char *d_ring = nullptr, *h_ring = nullptr;
+    char *h_down = nullptr;  // pinned staging for downloads (roots, opened values, query data): no pageable-memory path
+    static constexpr size_t DOWN_BYTES = 4u << 20;
     size_t ring_bytes = 0, ring_pos = 0;
     bool fail(const char *fmt, ...);
 };

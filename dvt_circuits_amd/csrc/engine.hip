@@ -75,6 +75,7 @@ hipError_t Engine::init(int dev) {
     ring_bytes = 16u << 20;
     if (e == hipSuccess) e = hipMalloc(&d_ring, ring_bytes);
     if (e == hipSuccess) e = hipHostMalloc(&h_ring, ring_bytes);
+    if (e == hipSuccess) e = hipHostMalloc(&h_down, DOWN_BYTES);
     return e;
 }
 void Engine::shutdown() {
@@ -84,6 +85,8 @@ void Engine::shutdown() {
     ntt_tables_destroy(&tabs);
     if (d_ring) (void)hipFree(d_ring);
     if (h_ring) (void)hipHostFree(h_ring);
+    if (h_down) (void)hipHostFree(h_down);
+    h_down = nullptr;
     if (stream) (void)hipStreamDestroy(stream);
     d_ring = h_ring = nullptr;
     stream = nullptr;
@@ -105,6 +108,12 @@ const void *Engine::upload(const void *host, size_t bytes) {
     return r;
 }
 bool Engine::download(void *host, const void *dev, size_t bytes) {
+    if (bytes <= DOWN_BYTES && h_down) {  // through pinned memory: a pageable destination makes the runtime stage and block
+        HIPCHK(hipMemcpyAsync(h_down, dev, bytes, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        memcpy(host, h_down, bytes);
+        return true;
+    }
     HIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     return true;
@@ -511,6 +520,7 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
     if (!d_beta_f64) return false;
     mats.clear();
     uint32_t perm_hmax = 0;
+    size_t n_cumsum = 0;
     for (auto &s : cs) {
         if (!s.d->perm_ext_w) continue;
         const size_t bw = 4 * (size_t)s.d->perm_ext_w;
@@ -522,11 +532,11 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
         uint32_t *scan_scratch;
         ALLOC(scan_scratch, uint32_t, prefix_sum_scratch_words(4, s.n));
         HIPCHK(launch_prefix_sum_columns(stream, phi, 4, s.n, scan_scratch));
-        uint32_t cw[4];
+        // the cumulative sum is only needed for the transcript, after the permutation tree: its four words are copied
+        // asynchronously into the tail of the pinned staging buffer and read after the next synchronisation
+        uint32_t *cw = reinterpret_cast<uint32_t *>(h_down + DOWN_BYTES - 4096) + 4 * n_cumsum++;
         for (int k = 0; k < 4; k++)
             HIPCHK(hipMemcpyAsync(&cw[k], phi + (size_t)k * s.n + s.n - 1, 4, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
-        for (int k = 0; k < 4; k++) s.cumsum.c[k] = Fp::raw(cw[k]);
         HIPCHK(lde(s.perm, d_scratch, s.perm_lde, (uint32_t)bw, s.log_n, 0));
         mats.push_back({s.perm_lde, (uint32_t)bw, s.log_n + 1});
         perm_hmax = std::max(perm_hmax, s.log_n + 1);
@@ -538,6 +548,16 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
         if (!commit(mats, d_perm_tree)) return false;
         if (!download(rootw, tree_root(d_perm_tree, perm_hmax), 32)) return false;
         pf.perm_root = digest_from_words(rootw);
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    {
+        const uint32_t *cw = reinterpret_cast<const uint32_t *>(h_down + DOWN_BYTES - 4096);
+        size_t at = 0;
+        for (auto &s : cs) {
+            if (!s.d->perm_ext_w) continue;
+            for (int k = 0; k < 4; k++) s.cumsum.c[k] = Fp::raw(cw[4 * at + k]);
+            at++;
+        }
     }
     ch.observe(pf.perm_root);
     for (auto &s : cs) ch.observe(s.cumsum);
@@ -708,21 +728,42 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
     struct Layer { Fp4 *v; uint32_t *tree; uint32_t log_m; };
     std::vector<Layer> layers;
     Fp4 *cur = ro[hmax];
-    for (uint32_t lm = hmax; lm > 1; lm--) {
+    // The transcript steps of the commit phase run on the device (fri_challenge_kernel): observe(root), sample beta.
+    // The host transcript is in the state those steps assume (alpha_fri was just sampled: no pending input); it gets the
+    // final sponge state and all the roots back with ONE download after the last round instead of one per round.
+    if (!ch.input.empty()) return fail("prove: internal error, transcript has pending input before FRI");
+    const uint32_t n_rounds = hmax > 1 ? hmax - 1 : 0;
+    uint32_t *d_fs;   // [16] sponge state, then n_rounds x [8] roots
+    Fp4 *d_betas;
+    ALLOC(d_fs, uint32_t, 16 + 8 * (size_t)n_rounds + 8);
+    ALLOC(d_betas, Fp4, (size_t)n_rounds + 1);
+    {
+        uint32_t st16[16];
+        for (int k = 0; k < 16; k++) st16[k] = ch.state[k].v;
+        const void *src = upload(st16, sizeof st16);
+        if (!src) return false;
+        HIPCHK(hipMemcpyAsync(d_fs, src, sizeof st16, hipMemcpyDeviceToDevice, stream));
+    }
+    uint32_t round = 0;
+    for (uint32_t lm = hmax; lm > 1; lm--, round++) {
         Layer L{cur, nullptr, lm};
         ALLOC(L.tree, uint32_t, tree_words(lm - 1));
         HIPCHK(launch_fri_leaves(stream, cur, lm, L.tree));
         if (!commit_tree_levels(L.tree, lm - 1)) return false;
-        if (!download(rootw, tree_root(L.tree, lm - 1), 32)) return false;
-        Digest root = digest_from_words(rootw);
-        pf.fri_roots.push_back(root);
-        ch.observe(root);
-        Fp4 fold_beta = ch.sample_ext();
+        HIPCHK(launch_fri_challenge(stream, tree_root(L.tree, lm - 1), d_fs, d_betas + round, d_fs + 16 + 8 * (size_t)round));
         Fp4 *nxt;
         ALLOC(nxt, Fp4, (size_t)1 << (lm - 1));
-        HIPCHK(launch_fri_fold(stream, tabs, cur, nxt, ro[lm - 1], fold_beta, lm));
+        HIPCHK(launch_fri_fold(stream, tabs, cur, nxt, ro[lm - 1], Fp4::zero(), lm, d_betas + round));
         layers.push_back(L);
         cur = nxt;
+    }
+    if (n_rounds) {
+        std::vector<uint32_t> fs(16 + 8 * (size_t)n_rounds);
+        if (!download(fs.data(), d_fs, fs.size() * 4)) return false;
+        for (uint32_t r = 0; r < n_rounds; r++) pf.fri_roots.push_back(digest_from_words(&fs[16 + 8 * (size_t)r]));
+        for (int k = 0; k < 16; k++) ch.state[k] = Fp::raw(fs[k]);
+        ch.input.clear();
+        ch.output.assign(ch.state, ch.state + 4);   // the squeezed rate minus the four elements beta popped from its back
     }
     {
         uint32_t fw[8];

@@ -243,11 +243,13 @@ hipError_t launch_reduced_opening(hipStream_t st, const NttTables &tabs, const u
 
 // ------------------------------------------------------------------ K8: fold + layer leaves
 // out[i] = (v[i] + v[i+h])/2 + beta * (v[i] - v[i+h]) / (2 w_M^i)  (+ ro[i])
-__global__ void __launch_bounds__(256) fri_fold_kernel(const Fp4 *v, Fp4 *out, const Fp4 *ro, Fp4 beta, uint32_t log_m,
-                                                      Fp inv2, NttTables tabs) {
+// (beta comes from device memory when beta_dev is given: the challenge of a FRI round is derived on the device)
+__global__ void __launch_bounds__(256) fri_fold_kernel(const Fp4 *v, Fp4 *out, const Fp4 *ro, Fp4 beta, const Fp4 *beta_dev,
+                                                      uint32_t log_m, Fp inv2, NttTables tabs) {
     const size_t half = (size_t)1 << (log_m - 1);
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
+    if (beta_dev) beta = load_ext(beta_dev);
     Fp4 lo = load_ext(v + i), hi = load_ext(v + i + half);
     Fp xinv = i ? root_pow24f(tabs, (uint32_t)(2 * half - i) << (24 - log_m)) : Fp::one();
     Fp4 r = (lo + hi) * inv2 + beta * ((lo - hi) * (inv2 * xinv));
@@ -255,10 +257,30 @@ __global__ void __launch_bounds__(256) fri_fold_kernel(const Fp4 *v, Fp4 *out, c
     store_ext(out + i, r);
 }
 hipError_t launch_fri_fold(hipStream_t st, const NttTables &tabs, const Fp4 *d_v, Fp4 *d_out, const Fp4 *d_ro, Fp4 beta,
-                           uint32_t log_m) {
+                           uint32_t log_m, const Fp4 *d_beta) {
     size_t half = (size_t)1 << (log_m - 1);
     Fp inv2 = inv(Fp::two());
-    fri_fold_kernel<<<(unsigned)((half + 255) / 256), 256, 0, st>>>(d_v, d_out, d_ro, beta, log_m, inv2, tabs);
+    fri_fold_kernel<<<(unsigned)((half + 255) / 256), 256, 0, st>>>(d_v, d_out, d_ro, beta, d_beta, log_m, inv2, tabs);
+    return hipGetLastError();
+}
+// One round of the FRI commit phase of the transcript, on the device (challenger.h semantics with an empty input
+// buffer: observe(root) fills the rate exactly, one duplexing, sample_ext pops the squeezed rate from the back):
+//   state[0..8) <- root;  state <- Poseidon2(state);  beta = (state[7], state[6], state[5], state[4]).
+// Removes a device->host->device round trip per FRI round.  The root is also copied to roots_out for the proof.
+__global__ void __launch_bounds__(64) fri_challenge_kernel(const uint32_t *root, uint32_t *state, Fp4 *beta_out, uint32_t *root_out) {
+    const uint32_t e = threadIdx.x & 15;
+    const p2f::CoopConsts k = p2f::coop_consts(e);
+    const uint32_t w_in = e < 8 ? root[e] : state[e];
+    const double s = p2f::coop_permute(p2f::from_mont(w_in), k);
+    const uint32_t w = p2f::to_mont(s);
+    if (threadIdx.x < 16) {
+        state[e] = w;
+        if (e < 8) root_out[e] = w_in;
+        if (e >= 4 && e < 8) reinterpret_cast<uint32_t *>(beta_out)[7 - e] = w;
+    }
+}
+hipError_t launch_fri_challenge(hipStream_t st, const uint32_t *d_root, uint32_t *d_state, Fp4 *d_beta_out, uint32_t *d_root_out) {
+    fri_challenge_kernel<<<1, 64, 0, st>>>(d_root, d_state, d_beta_out, d_root_out);
     return hipGetLastError();
 }
 // digest[i] = sponge(v[i] || v[i+half])  (8 words = one permutation)

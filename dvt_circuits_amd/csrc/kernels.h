@@ -65,7 +65,9 @@ hipError_t launch_reduced_opening(hipStream_t st, const NttTables &tabs, const u
                                   uint32_t n_all, uint32_t log_m, const double *d_alpha_pows_f64, Fp4 sz_all, Fp4 sz_two, Fp4 zeta,
                                   Fp4 zeta_next, Fp4 alpha_shift, Fp4 *d_out);
 hipError_t launch_fri_fold(hipStream_t st, const NttTables &tabs, const Fp4 *d_v, Fp4 *d_out, const Fp4 *d_ro, Fp4 beta,
-                           uint32_t log_m);
+                           uint32_t log_m, const Fp4 *d_beta = nullptr);
+// transcript step of one FRI round on the device: see fri.hip
+hipError_t launch_fri_challenge(hipStream_t st, const uint32_t *d_root, uint32_t *d_state, Fp4 *d_beta_out, uint32_t *d_root_out);
 hipError_t launch_fri_leaves(hipStream_t st, const Fp4 *d_v, uint32_t log_m, uint32_t *d_digests);
 hipError_t launch_gather_rows(hipStream_t st, const uint32_t *const *d_cols, const uint32_t *d_log_h, uint32_t ncols,
                               const uint32_t *d_idx, uint32_t nq, uint32_t *d_out);

@@ -20,3 +20,7 @@ for g, x, y in gaps:
     hist[(x, y)] = hist.get((x, y), 0) + max(g, 0)
 for (x, y), g in sorted(hist.items(), key=lambda kv: -kv[1])[:14]:
     print("  %8.1f us idle in total between %s -> %s" % (g / 1e3, x, y))
+print("largest single gaps (offset from the first kernel of the proof):")
+single = sorted(((win[i + 1][0] - win[i][1], win[i][1] - win[0][0], win[i][2], win[i + 1][2]) for i in range(len(win) - 1)), reverse=True)
+for g, at, x, y in single[:25]:
+    print("  %7.1f us at %7.2f ms  %s -> %s" % (g / 1e3, at / 1e6, x, y))
