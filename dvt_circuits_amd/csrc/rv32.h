@@ -108,7 +108,6 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
     auto F = [&](uint32_t bit) -> uint32_t { return (fl >> bit) & 1u; };
     auto B = [](uint32_t w, int i) -> uint32_t { return (w >> (8 * i)) & 0xffu; };
     const uint32_t clk = 4 * (row + 1);
-    s.put(RV32_CPU_is_real, 1);
     s.put(RV32_CPU_clk, clk);
     s.put(RV32_CPU_pc, in.pc);
     s.put(RV32_CPU_next_pc, r.next_pc);
@@ -123,10 +122,12 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
         s.put(RV32_CPU_c_0 + i, B(r.c, i));
         s.put(RV32_CPU_pa_prev_0 + i, B(r.pa_prev, i));
     }
-    s.put(RV32_CPU_tgt, in.tgt);
-    s.put(RV32_CPU_alu_op, in.alu_op);
+    s.put(RV32_CPU_aux, in.tgt + in.alu_op);   // target of the control-flow families / alu-bus opcode of F_ALU rows: never both
     s.put(RV32_CPU_pv_idx, r.pv_idx);
-    for (uint32_t k = 0; k < N_FLAGS; k++) s.put(RV32_CPU_rd_en + k, F(k));
+    // flag columns: rd_en, imm_c, then the family flags in FLAGS order (rs1_en, rs2_en and is_real are linear in those)
+    s.put(RV32_CPU_rd_en, F(F_RD_EN));
+    s.put(RV32_CPU_imm_c, F(F_IMM_C));
+    for (uint32_t k = F_ADD; k < N_FLAGS; k++) s.put(RV32_CPU_is_add + (k - F_ADD), F(k));
     s.prog(r.idx);
     // register ports
     uint32_t pb_hi = 0, pc_hi = 0, pa_hi = 0, m_hi = 0;

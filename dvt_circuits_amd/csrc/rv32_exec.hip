@@ -397,8 +397,7 @@ void build_prep(const Program &prog, HostPrep *out) {
         auto put = [&](int col, uint32_t v) { P0[(size_t)col * np + r] = v; };
         put(RV32_PROGRAM_P_pc, in.pc); put(RV32_PROGRAM_P_rd, in.rd); put(RV32_PROGRAM_P_rs1, in.rs1); put(RV32_PROGRAM_P_rs2, in.rs2);
         for (int i = 0; i < 4; i++) { put(RV32_PROGRAM_P_imm_0 + i, (in.imm >> (8 * i)) & 0xff); put(RV32_PROGRAM_P_off_0 + i, (in.off >> (8 * i)) & 0xff); }
-        put(RV32_PROGRAM_P_tgt, in.tgt);
-        put(RV32_PROGRAM_P_alu_op, in.alu_op);
+        put(RV32_PROGRAM_P_aux, in.tgt + in.alu_op);
         for (uint32_t k = 0; k < N_FLAGS; k++) put(RV32_PROGRAM_P_rd_en + k, (in.flags >> k) & 1);
     }
     // byte table

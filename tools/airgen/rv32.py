@@ -47,8 +47,9 @@ FLAGS = [
     "is_lb", "is_lbu", "is_lh", "is_lhu", "is_sb", "is_sh",
     "is_alu",   # the result comes from another chip over the "alu" bus (alu_op selects it)
 ]
-# instruction tuple on the program bus: pc, rd, rs1, rs2, imm[4], off[4], tgt, alu_op, flags...
-N_INSTR_FIELDS = 1 + 3 + 4 + 4 + 1 + 1 + len(FLAGS)
+# instruction tuple on the program bus: pc, rd, rs1, rs2, imm[4], off[4], aux, flags...
+# (aux = branch / jump target for the control-flow families, alu-bus opcode for is_alu rows: never both)
+N_INSTR_FIELDS = 1 + 3 + 4 + 4 + 1 + len(FLAGS)
 
 PUB_START_PC, PUB_NEXT_PC, PUB_EXIT_CODE, PUB_SHARD, PUB_IS_LAST, PUB_PV_START, PUB_PV_END = 0, 1, 2, 3, 4, 5, 6
 N_PUB = 7
@@ -58,7 +59,7 @@ UNION_W = 26
 def build_program():
     ch = Chip("program")
     fields = [ch.prep("pc"), ch.prep("rd"), ch.prep("rs1"), ch.prep("rs2")]
-    fields += ch.preps("imm", 4) + ch.preps("off", 4) + [ch.prep("tgt"), ch.prep("alu_op")]
+    fields += ch.preps("imm", 4) + ch.preps("off", 4) + [ch.prep("aux")]
     fields += [ch.prep(f) for f in FLAGS]
     mult = ch.col("mult")
     ch.receive("program", fields, mult)
@@ -82,10 +83,23 @@ def build_byte():
 
 def build_cpu():
     ch = Chip("cpu")
-    is_real, clk, pc, next_pc = ch.col("is_real"), ch.col("clk"), ch.col("pc"), ch.col("next_pc")
+    clk, pc, next_pc = ch.col("clk"), ch.col("pc"), ch.col("next_pc")
     rd, rs1, rs2 = ch.col("rd"), ch.col("rs1"), ch.col("rs2")
-    imm, off, tgt, alu_op = ch.cols("imm", 4), ch.cols("off", 4), ch.col("tgt"), ch.col("alu_op")
-    F = {f: ch.col(f) for f in FLAGS}
+    imm, off, aux = ch.cols("imm", 4), ch.cols("off", 4), ch.col("aux")
+    tgt = alu_op = aux
+    # Flags that are linear in other flags are expressions, not columns (104 main columns = 13 sponge blocks exactly):
+    #   is_real = sum of the family flags (a real row belongs to exactly one family; the program table, whose rows
+    #             the fetch lookup must match with this very multiplicity, guarantees it);
+    #   rs1_en  = every family that reads rs1;
+    #   rs2_en  = every family that has a c operand, minus the immediate forms (c = rs2 or c = imm, never both).
+    FAMILY = [f for f in FLAGS if f not in ("rd_en", "rs1_en", "rs2_en", "imm_c")]
+    F = {f: ch.col(f) for f in FLAGS if f not in ("rs1_en", "rs2_en")}
+    NO_RS1 = ("is_lui", "is_jal")
+    NO_C = ("is_lui", "is_jal", "is_jalr", "is_lw", "is_lb", "is_lbu", "is_lh", "is_lhu")
+    is_real = esum(F[f] for f in FAMILY)
+    is_real_next = esum(F[f].next() for f in FAMILY)
+    F["rs1_en"] = esum(F[f] for f in FAMILY if f not in NO_RS1)
+    F["rs2_en"] = esum(F[f] for f in FAMILY if f not in NO_C) - F["imm_c"]
     a, b, c = ch.cols("a", 4), ch.cols("b", 4), ch.cols("c", 4)
     # register ports: previous timestamp + 24-bit difference (16 + 8 bit limbs)
     pb_ts, pb_lo, pb_hi = ch.col("pb_ts"), ch.col("pb_lo"), ch.col("pb_hi")
@@ -101,19 +115,19 @@ def build_cpu():
 
     # ---------------- row bookkeeping
     ch.assert_bool(is_real)
-    ch.assert_zero(is_real.next() * (1 - is_real), "trans")            # real rows first
+    ch.assert_zero(is_real_next * (1 - is_real), "trans")            # real rows first
     ch.assert_eq(is_real, 1, "first")
     ch.assert_eq(pc, ch.pub(PUB_START_PC), "first")
     ch.assert_eq(clk, 4, "first")
-    ch.assert_zero(is_real.next() * (clk.next() - clk - 4), "trans")
-    ch.assert_zero(is_real.next() * (pc.next() - next_pc), "trans")
-    ch.assert_zero((is_real - is_real.next()) * (next_pc - ch.pub(PUB_NEXT_PC)), "trans")
+    ch.assert_zero(is_real_next * (clk.next() - clk - 4), "trans")
+    ch.assert_zero(is_real_next * (pc.next() - next_pc), "trans")
+    ch.assert_zero((is_real - is_real_next) * (next_pc - ch.pub(PUB_NEXT_PC)), "trans")
     ch.assert_zero(is_real * (next_pc - ch.pub(PUB_NEXT_PC)), "last")
-    for f in FLAGS:                                                     # padding rows do nothing
+    for f in ("rd_en", "imm_c"):                                        # padding rows do nothing
         ch.assert_zero((1 - is_real) * F[f])
 
     # ---------------- fetch
-    ch.send("program", [pc, rd, rs1, rs2] + imm + off + [tgt, alu_op] + [F[f] for f in FLAGS], is_real)
+    ch.send("program", [pc, rd, rs1, rs2] + imm + off + [aux] + [F[f] for f in FLAGS], is_real)
     # families that live in their own chips (shifts): the row only ships (op, a, b, c) over the alu bus;
     # the receiving chip constrains a and range-checks its bytes
     ch.send("alu", [alu_op] + a + b + c, F["is_alu"])
