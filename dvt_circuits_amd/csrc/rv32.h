@@ -198,9 +198,9 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
         }
         for (int k = 0; k < 8; k++) {
             s.put(U + k, pbyte[k]);
-            s.put(U + 8 + k, pcarry[k]);
+            if (k < 7) s.put(U + 8 + k, pcarry[k]);   // the carry out of byte 7 is 0 (a 64-bit product), not a column
         }
-        for (int k = 0; k < 8; k++) s.byte(B_U16 - 1, pcarry[k]);
+        for (int k = 0; k < 7; k++) s.byte(B_U16 - 1, pcarry[k]);
         uint64_t pr = (uint64_t)b * c;
         for (int k = 0; k < 4; k++) s.byte(B_RANGE - 1, (((uint32_t)(pr >> (16 * k)) & 0xff) << 8) | ((uint32_t)(pr >> (16 * k + 8)) & 0xff));
     } else if (F(F_LW) | F(F_SW) | F(F_JALR) | F(F_LB) | F(F_LBU) | F(F_LH) | F(F_LHU) | F(F_SB) | F(F_SH)) {

@@ -203,7 +203,8 @@ def build_cpu():
     ch.assert_zero(sel_branch * (next_pc - pc - 4) - taken * (tgt - pc - 4))
 
     # MUL / MULHU : u[0..7] product bytes, u[8..15] carries
-    prod, mcy = U[0:8], U[8:16]
+    # (the product of two 32-bit words fits 8 bytes: the carry out of byte 7 is the constant 0, not a witness)
+    prod, mcy = U[0:8], U[8:15] + [Expr.const(0)]
     for k in range(8):
         terms = esum(b[i] * c[k - i] for i in range(4) if 0 <= k - i < 4)
         cin = mcy[k - 1] if k else Expr.const(0)
@@ -213,7 +214,7 @@ def build_cpu():
         ch.assert_zero(F["is_mulhu"] * (a[i] - prod[4 + i]))
     for k in range(4):
         ch.send("byte", [B_RANGE, 0, prod[2 * k], prod[2 * k + 1]], sel_mul)
-    for k in range(8):
+    for k in range(7):
         ch.send("byte", [B_U16, 0, mcy[k], 0], sel_mul)
 
     # LUI / AUIPC / JAL / JALR link : a := imm   (pc-relative constants are folded at decode time)
