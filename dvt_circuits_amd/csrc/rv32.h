@@ -196,13 +196,14 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
             pcarry[k] = t >> 8;
             acc = t >> 8;
         }
-        for (int k = 0; k < 8; k++) {
-            s.put(U + k, pbyte[k]);
-            if (k < 7) s.put(U + 8 + k, pcarry[k]);   // the carry out of byte 7 is 0 (a 64-bit product), not a column
-        }
+        // u[0..3] = the half of the product that is not the result (the result half is `a`, range-checked below with
+        // the other arithmetic families); u[4..10] = carries out of bytes 0..6 (the one out of byte 7 is 0)
+        const int xo = F(F_MUL) ? 4 : 0;
+        for (int i = 0; i < 4; i++) s.put(U + i, pbyte[xo + i]);
+        for (int k = 0; k < 7; k++) s.put(U + 4 + k, pcarry[k]);
         for (int k = 0; k < 7; k++) s.byte(B_U16 - 1, pcarry[k]);
-        uint64_t pr = (uint64_t)b * c;
-        for (int k = 0; k < 4; k++) s.byte(B_RANGE - 1, (((uint32_t)(pr >> (16 * k)) & 0xff) << 8) | ((uint32_t)(pr >> (16 * k + 8)) & 0xff));
+        s.byte(B_RANGE - 1, (pbyte[xo] << 8) | pbyte[xo + 1]);
+        s.byte(B_RANGE - 1, (pbyte[xo + 2] << 8) | pbyte[xo + 3]);
     } else if (F(F_LW) | F(F_SW) | F(F_JALR) | F(F_LB) | F(F_LBU) | F(F_LH) | F(F_LHU) | F(F_SB) | F(F_SH)) {
         uint32_t sum = b + in.off, cin = 0;
         for (int i = 0; i < 4; i++) {
@@ -217,9 +218,9 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
         if (F(F_JALR)) {
             s.put(U + 8, sum & 1);
         } else {
-            for (int i = 0; i < 4; i++) { s.put(U + 8 + i, B(r.m_val, i)); s.put(U + 12 + i, B(r.m_prev, i)); }
+            for (int i = 0; i < 4; i++) { s.put(U + 9 + i, B(r.m_val, i)); s.put(U + 13 + i, B(r.m_prev, i)); }
             uint32_t d = gap(r.m_sh, r.m_ts, clk + 2);
-            s.put(U + 16, r.m_ts); s.put(U + 17, d & 0xffff); m_hi = d >> 16;
+            s.put(U + 17, r.m_ts); s.put(U + 8, d & 0xffff); m_hi = d >> 16;
             s.put(U + 18, m_hi); s.put(U + 19, r.m_sh); s.put(U + 20, r.m_sh == shard);
             s.byte(B_U16 - 1, d & 0xffff);
             s.byte(B_AND - 1, (B(sum, 0) << 8) | 3);

@@ -202,20 +202,21 @@ def build_cpu():
              + (F["is_bge"] + F["is_bgeu"]) * (1 - lt))
     ch.assert_zero(sel_branch * (next_pc - pc - 4) - taken * (tgt - pc - 4))
 
-    # MUL / MULHU : u[0..7] product bytes, u[8..15] carries
-    # (the product of two 32-bit words fits 8 bytes: the carry out of byte 7 is the constant 0, not a witness)
-    prod, mcy = U[0:8], U[8:15] + [Expr.const(0)]
+    # MUL / MULHU : the half of the 64-bit product that is NOT the result lives in u[0..3] (x), the result half is `a`
+    # itself; u[4..10] = the carries out of bytes 0..6 (the carry out of byte 7 of a 64-bit product is the constant 0).
+    # Lookups are shared with other families wherever the tuple expressions coincide (the families are mutually
+    # exclusive, so one interaction with the sum of the selectors serves both): the range check of x is the adder
+    # family's range check of u[0..3], the range check of `a` is the common one, carry 4 shares the U16 slot of the
+    # memory family's timestamp limb in u[8].
+    x, mcy = U[0:4], U[4:11] + [Expr.const(0)]
     for k in range(8):
         terms = esum(b[i] * c[k - i] for i in range(4) if 0 <= k - i < 4)
         cin = mcy[k - 1] if k else Expr.const(0)
-        ch.assert_zero(sel_mul * (terms + cin - prod[k] - 256 * mcy[k]))
-    for i in range(4):
-        ch.assert_zero(F["is_mul"] * (a[i] - prod[i]))
-        ch.assert_zero(F["is_mulhu"] * (a[i] - prod[4 + i]))
-    for k in range(4):
-        ch.send("byte", [B_RANGE, 0, prod[2 * k], prod[2 * k + 1]], sel_mul)
+        pk = F["is_mul"] * a[k] + F["is_mulhu"] * x[k] if k < 4 else F["is_mul"] * x[k - 4] + F["is_mulhu"] * a[k - 4]
+        ch.assert_zero(sel_mul * (terms + cin - 256 * mcy[k]) - pk)
     for k in range(7):
-        ch.send("byte", [B_U16, 0, mcy[k], 0], sel_mul)
+        if k != 4:
+            ch.send("byte", [B_U16, 0, mcy[k], 0], sel_mul)
 
     # LUI / AUIPC / JAL / JALR link : a := imm   (pc-relative constants are folded at decode time)
     sel_const = F["is_lui"] + F["is_jal"] + F["is_jalr"]
@@ -229,18 +230,18 @@ def build_cpu():
         cin = acy[i - 1] if i else Expr.const(0)
         ch.assert_zero(sel_adder * (b[i] + off[i] + cin - s[i] - 256 * acy[i]))
         ch.assert_zero(sel_adder * (acy[i] * (acy[i] - 1)))
-    ch.send("byte", [B_RANGE, 0, s[0], s[1]], sel_adder)
-    ch.send("byte", [B_RANGE, 0, s[2], s[3]], sel_adder)
+    ch.send("byte", [B_RANGE, 0, s[0], s[1]], sel_adder + sel_mul)      # (MUL / MULHU: the bytes of x)
+    ch.send("byte", [B_RANGE, 0, s[2], s[3]], sel_adder + sel_mul)
     ch.send("byte", [B_LTU, 1, s[3], 0x40], sel_adder)        # address / target < 2^30
     # JALR: u[8] = low bit cleared from the target
     jl = U[8]
     ch.assert_zero(F["is_jalr"] * (jl * (jl - 1)))
     ch.assert_zero(F["is_jalr"] * (next_pc - word(s) + jl))
-    # loads / stores: u[8..11] memory word after, u[12..15] before, u[16] prev clk, u[17] lo, u[18] hi,
-    # u[19] prev shard, u[20] same-shard flag, u[21..23] byte-offset one-hot (offset 0 = none set),
+    # loads / stores: u[8] low limb of the timestamp difference, u[9..12] memory word after, u[13..16] before, u[17] prev clk,
+    # u[18] hi limb, u[19] prev shard, u[20] same-shard flag, u[21..23] byte-offset one-hot (offset 0 = none set),
     # u[24] the byte whose sign extends a sub-word load, u[25] its sign bit.
     # The access always moves the whole aligned word on the memory bus; sub-word forms select / patch bytes.
-    mv, mp, m_ts, m_lo, m_hi, m_sh, m_same = U[8:12], U[12:16], U[16], U[17], U[18], U[19], U[20]
+    m_lo, mv, mp, m_ts, m_hi, m_sh, m_same = U[8], U[9:13], U[13:17], U[17], U[18], U[19], U[20]
     o1, o2, o3, sb, sgn = U[21], U[22], U[23], U[24], U[25]
     o0 = 1 - o1 - o2 - o3
     oh = [o0, o1, o2, o3]
@@ -257,7 +258,7 @@ def build_cpu():
     ch.assert_zero(sel_mem * (m_same * (m_same - 1)))
     ch.assert_zero(sel_mem * (m_same * (shard - m_sh)))
     ch.assert_zero(sel_mem * (m_same * (clk + 2 - m_ts - 1) + (1 - m_same) * (shard - m_sh - 1) - m_lo - 65536 * m_hi))
-    ch.send("byte", [B_U16, 0, m_lo, 0], sel_mem)
+    ch.send("byte", [B_U16, 0, m_lo, 0], sel_mem + sel_mul)             # (MUL / MULHU: carry 4, also in u[8])
     sel_load = F["is_lw"] + sel_loadsub
     for i in range(4):
         ch.assert_zero(F["is_lw"] * (a[i] - mv[i]))
