@@ -23,7 +23,8 @@ constexpr uint32_t LDE_MAX_LOG = 23;
 struct NttTables {
     uint32_t *base = nullptr;
     const uint32_t *tw_hi = nullptr, *tw_lo = nullptr, *sh_hi = nullptr, *sh_lo = nullptr;
-    const uint32_t *lde_tw = nullptr, *lde_scale = nullptr;
+    const uint32_t *lde_tw = nullptr, *lde_scale = nullptr;      // Montgomery words
+    const uint32_t *lde_tw_c = nullptr, *lde_scale_c = nullptr;  // the same as centred canonical residues (two's complement)
 };
 hipError_t ntt_tables_create(NttTables *t);
 void ntt_tables_destroy(NttTables *t);

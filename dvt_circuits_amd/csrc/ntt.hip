@@ -28,8 +28,22 @@
 // words of a group, does 12 butterflies, scatters them back — one barrier per three
 // stages instead of per stage.
 #include "kernels.h"
+#include "poseidon2_f64.cuh"
 
 namespace dvt {
+
+// Arithmetic: the butterflies run on the FP64 pipe (see poseidon2_f64.cuh for the formulation: exact integers in
+// doubles, a modular product = 6 full-rate operations, additions unreduced).  Measured on the integer version of these
+// kernels: the time went into VALU issue slots (3-instruction modular add / sub, the non-multiply half of the Montgomery
+// product), not into the multiplier and not into LDS.  LDS tiles hold 32-bit signed residues in (-p, p); twiddles are
+// CANONICAL residues (the data words are Montgomery words: x~ * w mod p is the Montgomery word of x * w), one
+// conversion per LDS word on the way in, one reduction + conversion on the way out.
+using Lw = int32_t;
+__device__ __forceinline__ Lw to_lds(double x) { return (Lw)x; }                    // |x| < 2^31
+__device__ __forceinline__ uint32_t lds_to_word(Lw v) { return v < 0 ? (uint32_t)(v + (Lw)P) : (uint32_t)v; }
+// canonical residue of a Montgomery-form field element as a centred double (per-thread twiddle seeds)
+__device__ __forceinline__ double centred(Fp x) { return p2f::mm((double)x.v, p2f::MONT_RINV); }
+
 
 __device__ __forceinline__ Fp root_pow24(const NttTables &t, uint32_t e) {  // Omega^e, Omega of order 2^24
     return Fp::raw(t.tw_hi[e >> 12]) * Fp::raw(t.tw_lo[e & 4095]);
@@ -68,9 +82,14 @@ __device__ __forceinline__ uint32_t lane_block(uint32_t bw, uint32_t ell, uint32
 // Element (i, c) of a [2^L][2^log_cols] tile has logical index (i << log_cols) | c; the transform runs
 // over i for every c.  tw[swz(e << tw_shift)] = w_{2^L}^e.
 // DIF stages s .. s+R-1 (stage t pairs distance 2^(L-1-t), twiddle exponent (index mod half) << t).
-template <int R>
-__device__ __forceinline__ void dif_pass(Fp *sm, const Fp *tw, uint32_t L, uint32_t s, uint32_t tw_shift, uint32_t log_cols,
+// Geometry: the runtime arguments (L, s, tw_shift, log_cols) serve every size; with SL >= 0 the template arguments replace
+// them, every swizzled offset below folds to a literal and only the block / row part of an address is computed at run
+// time (measured: with runtime geometry the address arithmetic of a pass costs as many VALU slots as its butterflies).
+template <int R, int SL = -1, int SS = 0, int STW = 0, int SLC = 0>
+__device__ __forceinline__ void dif_pass(Lw *sm, const Lw *tw, uint32_t L_rt, uint32_t s_rt, uint32_t tw_shift_rt, uint32_t log_cols_rt,
                                          uint32_t tid, uint32_t nt) {
+    const uint32_t L = SL >= 0 ? (uint32_t)SL : L_rt, s = SL >= 0 ? (uint32_t)SS : s_rt;
+    const uint32_t tw_shift = SL >= 0 ? (uint32_t)STW : tw_shift_rt, log_cols = SL >= 0 ? (uint32_t)SLC : log_cols_rt;
     constexpr uint32_t G = 1u << R;
     const uint32_t lh_last = L - s - R, cmask = (1u << log_cols) - 1;
     const uint32_t ell = lh_last + log_cols, blk_bits = s;
@@ -83,9 +102,9 @@ __device__ __forceinline__ void dif_pass(Fp *sm, const Fp *tw, uint32_t L, uint3
         const uint32_t c = low & cmask, r = low >> log_cols;
         const uint32_t blk = lane_block<R>(w >> ell, ell, blk_bits);
         const uint32_t base = swz((((blk << (L - s)) | r) << log_cols) | c);
-        Fp v[G];
+        double v[G];
 #pragma unroll
-        for (uint32_t j = 0; j < G; j++) v[j] = sm[base ^ joff[j]];
+        for (uint32_t j = 0; j < G; j++) v[j] = (double)sm[base ^ joff[j]];
 #pragma unroll
         for (uint32_t t = 0; t < (uint32_t)R; t++) {
             const uint32_t dist = G >> (t + 1);
@@ -94,19 +113,21 @@ __device__ __forceinline__ void dif_pass(Fp *sm, const Fp *tw, uint32_t L, uint3
             for (uint32_t j = 0; j < G; j++) {
                 if (j & dist) continue;
                 const uint32_t twj = swz((((j & (dist - 1)) << lh_last) << (s + t)) << tw_shift);
-                Fp a = v[j], b = v[j + dist];
-                v[j] = a + b;
-                // a - b + p < 2p < 2^32 needs no reduction before the Montgomery product (2p * p < p * 2^32)
-                v[j + dist] = Fp::raw(Fp::reduce64((uint64_t)(a.v + (P - b.v)) * tw[twr ^ twj].v));
+                const double a = v[j], b = v[j + dist];
+                v[j] = a + b;                                            // grows by one bit per stage: < 2^34 after three
+                v[j + dist] = p2f::mm(a - b, (double)tw[twr ^ twj]);     // |a - b| < 2^35, |w| < 2^31: reduced again
             }
         }
+        // odd positions left the last stage through a product (already reduced); even ones are sums
 #pragma unroll
-        for (uint32_t j = 0; j < G; j++) sm[base ^ joff[j]] = v[j];
+        for (uint32_t j = 0; j < G; j++) sm[base ^ joff[j]] = to_lds((j & 1) ? v[j] : p2f::red(v[j]));
     }
 }
 // DIT stages s .. s+R-1 (stage t pairs distance 2^t, twiddle exponent (index mod 2^t) << (L-1-t)).
-template <int R>
-__device__ __forceinline__ void dit_pass(Fp *sm, const Fp *tw, uint32_t L, uint32_t s, uint32_t tw_shift, uint32_t tid, uint32_t nt) {
+template <int R, int SL = -1, int SS = 0, int STW = 0>
+__device__ __forceinline__ void dit_pass(Lw *sm, const Lw *tw, uint32_t L_rt, uint32_t s_rt, uint32_t tw_shift_rt, uint32_t tid, uint32_t nt) {
+    const uint32_t L = SL >= 0 ? (uint32_t)SL : L_rt, s = SL >= 0 ? (uint32_t)SS : s_rt;
+    const uint32_t tw_shift = SL >= 0 ? (uint32_t)STW : tw_shift_rt;
     constexpr uint32_t G = 1u << R;
     const uint32_t work = 1u << (L - R);
     const uint32_t blk_bits = L - R - s;
@@ -117,9 +138,9 @@ __device__ __forceinline__ void dit_pass(Fp *sm, const Fp *tw, uint32_t L, uint3
         const uint32_t r = g & ((1u << s) - 1);
         const uint32_t blk = lane_block<R>(g >> s, s, blk_bits);
         const uint32_t base = swz((blk << (s + R)) | r);
-        Fp v[G];
+        double v[G];
 #pragma unroll
-        for (uint32_t j = 0; j < G; j++) v[j] = sm[base ^ joff[j]];
+        for (uint32_t j = 0; j < G; j++) v[j] = (double)sm[base ^ joff[j]];
 #pragma unroll
         for (uint32_t t = 0; t < (uint32_t)R; t++) {
             const uint32_t dist = 1u << t;
@@ -128,17 +149,17 @@ __device__ __forceinline__ void dit_pass(Fp *sm, const Fp *tw, uint32_t L, uint3
             for (uint32_t j = 0; j < G; j++) {
                 if (j & dist) continue;
                 const uint32_t twj = swz((((j & (dist - 1)) << s) << (L - 1 - s - t)) << tw_shift);
-                Fp a = v[j], b = v[j + dist] * tw[twr ^ twj];
+                const double a = v[j], b = p2f::mm(v[j + dist], (double)tw[twr ^ twj]);   // |v| < 2^33
                 v[j] = a + b;
                 v[j + dist] = a - b;
             }
         }
 #pragma unroll
-        for (uint32_t j = 0; j < G; j++) sm[base ^ joff[j]] = v[j];
+        for (uint32_t j = 0; j < G; j++) sm[base ^ joff[j]] = to_lds(p2f::red(v[j]));
     }
 }
 template <bool DIF>
-__device__ __forceinline__ void run_stages(Fp *sm, const Fp *tw, uint32_t L, uint32_t first, uint32_t count, uint32_t tw_shift,
+__device__ __forceinline__ void run_stages(Lw *sm, const Lw *tw, uint32_t L, uint32_t first, uint32_t count, uint32_t tw_shift,
                                            uint32_t log_cols, uint32_t tid, uint32_t nt) {
     uint32_t s = first, left = count;
     while (left) {
@@ -156,6 +177,18 @@ __device__ __forceinline__ void run_stages(Fp *sm, const Fp *tw, uint32_t L, uin
     }
 }
 
+// the same with compile-time geometry: stages FIRST .. FIRST+COUNT-1 of a 2^L-point transform
+template <bool DIF, int L, int FIRST, int COUNT, int TWS, int LC>
+__device__ __forceinline__ void run_stages_static(Lw *sm, const Lw *tw, uint32_t tid, uint32_t nt) {
+    if constexpr (COUNT > 0) {
+        constexpr int R = COUNT >= 3 ? 3 : COUNT;
+        if constexpr (DIF) dif_pass<R, L, FIRST, TWS, LC>(sm, tw, 0, 0, 0, 0, tid, nt);
+        else dit_pass<R, L, FIRST, TWS>(sm, tw, 0, 0, 0, tid, nt);
+        __syncthreads();
+        run_stages_static<DIF, L, FIRST + R, COUNT - R, TWS, LC>(sm, tw, tid, nt);
+    }
+}
+
 // ---------------------------------------------------------------- P1 / P3
 // grid.x = row_stride >> log_cols (tiles along the contiguous axis), grid.y = column
 template <bool INVERSE>
@@ -164,30 +197,31 @@ __global__ void __launch_bounds__(1024) ntt_strided_kernel(const uint32_t *src, 
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t rows = 1u << log_rows, cols = 1u << log_cols, cmask = cols - 1;
     const uint32_t tile_elems = rows << log_cols;
-    Fp *sm = reinterpret_cast<Fp *>(lds);
-    Fp *tw = sm + tile_elems;  // rows/2 entries: w_rows^e
+    Lw *sm = reinterpret_cast<Lw *>(lds);
+    Lw *tw = sm + tile_elems;  // rows/2 entries: w_rows^e (canonical)
     uint32_t *col = data + (size_t)blockIdx.y * col_stride;
     const uint32_t *scol = src + (size_t)blockIdx.y * col_stride;
     const uint32_t c0 = blockIdx.x << log_cols;
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
 
-    for (uint32_t e = tid; e < rows / 2; e += nt) tw[swz(e)] = Fp::raw(tabs.lde_tw[rows / 2 - 1 + e]);
+    for (uint32_t e = tid; e < rows / 2; e += nt) tw[swz(e)] = (Lw)tabs.lde_tw_c[rows / 2 - 1 + e];
     for (uint32_t idx = tid; idx < tile_elems; idx += nt) {
         uint32_t r = idx >> log_cols, c = idx & cmask;
-        sm[swz(idx)] = Fp::raw(scol[(size_t)r * row_stride + c0 + c]);
+        sm[swz(idx)] = (Lw)scol[(size_t)r * row_stride + c0 + c];      // a word in [0, p) is a valid residue in (-p, p)
     }
     __syncthreads();
-    run_stages<true>(sm, tw, log_rows, 0, log_rows, 0, log_cols, tid, nt);  // forward DIF over the row index
+    // forward DIF over the row index (the two tile shapes of 2^21- and 2^22-row traces with literal geometry)
+    if (log_rows == 9 && log_cols == 4) run_stages_static<true, 9, 0, 9, 0, 4>(sm, tw, tid, nt);
+    else if (log_rows == 10 && log_cols == 4) run_stages_static<true, 10, 0, 10, 0, 4>(sm, tw, tid, nt);
+    else run_stages<true>(sm, tw, log_rows, 0, log_rows, 0, log_cols, tid, nt);
     for (uint32_t idx = tid; idx < tile_elems; idx += nt) {
         uint32_t q = idx >> log_cols, c = idx & cmask;
         uint32_t kf = bitrev(q, log_rows);
-        Fp val = sm[swz(idx)];
-        uint32_t orow;
+        const Lw val = sm[swz(idx)];
         // inverse: DFT with the output index negated; the four-step twiddle w_N^-(n2 k1) that belongs here is applied
         // by lde_block when it loads row k1 (there it is a geometric sequence per thread, here it would be a gather)
-        if (INVERSE) orow = (rows - kf) & (rows - 1);
-        else orow = kf;
-        col[(size_t)orow * row_stride + c0 + c] = val.v;
+        const uint32_t orow = INVERSE ? (rows - kf) & (rows - 1) : kf;
+        col[(size_t)orow * row_stride + c0 + c] = lds_to_word(val);
     }
 }
 
@@ -198,42 +232,45 @@ __global__ void __launch_bounds__(1024) lde_block_kernel(const uint32_t *in, uin
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t log_n2 = log_n - log_n1, n2 = 1u << log_n2, m2 = n2 * 2, log_m2 = log_n2 + 1;
     const uint32_t log_m = log_n + 1;
-    Fp *sm = reinterpret_cast<Fp *>(lds);
-    Fp *tw = sm + m2;  // n2 entries: w_M2^e, e < M2/2
+    Lw *sm = reinterpret_cast<Lw *>(lds);
+    Lw *tw = sm + m2;  // n2 entries: w_M2^e, e < M2/2 (canonical)
     const uint32_t k1 = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const uint32_t *src = in + ((size_t)blockIdx.y << log_n) + ((size_t)k1 << log_n2);
     uint32_t *dst = out + ((size_t)blockIdx.y << log_m) + ((size_t)k1 << log_m2);
 
     // twiddles w_M2^e and the position-dependent part of the coefficient scaling come from tables built once per
     // prover (coalesced reads) instead of two table gathers and a product per element
-    const uint32_t *W = tabs.lde_tw + (n2 - 1);
-    const uint32_t *T = tabs.lde_scale + ((size_t)(shift_mode * LDE_MAX_LOG + log_n) << 12);
-    for (uint32_t e = tid; e < n2; e += nt) tw[swz(e)] = Fp::raw(W[e]);
+    const uint32_t *W = tabs.lde_tw_c + (n2 - 1);
+    const uint32_t *T = tabs.lde_scale_c + ((size_t)(shift_mode * LDE_MAX_LOG + log_n) << 12);
+    for (uint32_t e = tid; e < n2; e += nt) tw[swz(e)] = (Lw)W[e];
     if (log_n1 == 0 || k1 == 0) {
-        for (uint32_t i = tid; i < n2; i += nt) sm[swz(i)] = Fp::raw(src[i]);
+        for (uint32_t i = tid; i < n2; i += nt) sm[swz(i)] = (Lw)src[i];
     } else if (tid < n2) {
-        // four-step twiddle between P1 and this transform: x[i] *= w_N^-(i k1), i = tid + t nt (i k1 < N)
+        // four-step twiddle between P1 and this transform: x[i] *= w_N^-(i k1), i = tid + t nt (i k1 < N):
+        // a geometric sequence per thread
         const uint32_t nn = 1u << log_n;
-        Fp cur = tid ? root_pow24(tabs, (nn - tid * k1) << (24 - log_n)) : Fp::one();
-        const Fp step = root_pow24(tabs, (nn - nt * k1) << (24 - log_n));  // nt <= n2 / 8, so 0 < nt * k1 < N
+        double cur = tid ? centred(root_pow24(tabs, (nn - tid * k1) << (24 - log_n))) : 1.0;
+        const double step = centred(root_pow24(tabs, (nn - nt * k1) << (24 - log_n)));  // nt <= n2 / 8, so 0 < nt * k1 < N
         for (uint32_t i = tid; i < n2; i += nt) {
-            sm[swz(i)] = Fp::raw(src[i]) * cur;
-            cur = cur * step;
+            sm[swz(i)] = to_lds(p2f::mm((double)src[i], cur));
+            cur = p2f::mm(cur, step);
         }
     }
     __syncthreads();
-    run_stages<true>(sm, tw, log_n2, 0, log_n2, 1, 0, tid, nt);  // forward DIF of size N2 (w_N2^e = tw[2e])
+    // forward DIF of size N2 (w_N2^e = tw[2e]); every trace of 2^12 rows or more has N2 = 2^12
+    if (log_n2 == 12) run_stages_static<true, 12, 0, 12, 1, 0>(sm, tw, tid, nt);
+    else run_stages<true>(sm, tw, log_n2, 0, log_n2, 1, 0, tid, nt);
     // position q holds DFT[bitrev(q)] = N * coeff[k], k = k1 + (k2 << log_n1), k2 = (N2 - bitrev(q)) mod N2.
     // The coefficient must be scaled by s^k / N (s = coset shift, mode 0; 1, mode 1; w_M^-1, mode 2):
     // s^k / N = s^k1 * T[q] with T[q] = s^(k2 << log_n1) / N; the per-block factor s^k1 commutes with the
     // (linear) M2-point transform and is folded into the output twiddle below.
     // Scale, then place at the bit-reversed slot of the zero-padded M2 array with the first DIT stage
     // (pairs (c,0) -> (c,c)) folded in.
-    Fp regs[16];
+    Lw regs[16];
 #pragma unroll
     for (int t = 0; t < 16; t++) {
         uint32_t q = tid + t * nt;
-        if (q < n2) regs[t] = sm[swz(q)] * Fp::raw(T[q]);
+        if (q < n2) regs[t] = to_lds(p2f::mm((double)sm[swz(q)], (double)(Lw)T[q]));
     }
     __syncthreads();
 #pragma unroll
@@ -247,20 +284,23 @@ __global__ void __launch_bounds__(1024) lde_block_kernel(const uint32_t *in, uin
         }
     }
     __syncthreads();
-    run_stages<false>(sm, tw, log_m2, 1, log_m2 - 1, 0, 0, tid, nt);  // remaining DIT stages of the M2-point transform
+    // remaining DIT stages of the M2-point transform
+    if (log_n2 == 12) run_stages_static<false, 13, 1, 12, 0, 0>(sm, tw, tid, nt);
+    else run_stages<false>(sm, tw, log_m2, 1, log_m2 - 1, 0, 0, tid, nt);
     if (log_n1 == 0) {  // single block: k1 = 0, nothing left to multiply
-        for (uint32_t j2 = tid; j2 < m2; j2 += nt) dst[j2] = sm[swz(j2)].v;
+        for (uint32_t j2 = tid; j2 < m2; j2 += nt) dst[j2] = lds_to_word(sm[swz(j2)]);
         return;
     }
     if (tid >= m2) return;
     // out[j2] = val * s^k1 * w_M^(j2 k1); j2 = tid + t nt: a geometric sequence per thread (j2 k1 < M)
-    Fp cur = root_pow24(tabs, (tid * k1) << (24 - log_m));
-    if (shift_mode == 0) cur = cur * shift_pow(tabs, k1);
-    else if (shift_mode == 2 && k1) cur = cur * root_pow24(tabs, ((2u << log_n) - k1) << (24 - log_m));
-    const Fp step = root_pow24(tabs, (nt * k1) << (24 - log_m));  // nt <= m2, so nt * k1 < M
+    Fp c0 = root_pow24(tabs, (tid * k1) << (24 - log_m));
+    if (shift_mode == 0) c0 = c0 * shift_pow(tabs, k1);
+    else if (shift_mode == 2 && k1) c0 = c0 * root_pow24(tabs, ((2u << log_n) - k1) << (24 - log_m));
+    double cur = centred(c0);
+    const double step = centred(root_pow24(tabs, (nt * k1) << (24 - log_m)));  // nt <= m2, so nt * k1 < M
     for (uint32_t j2 = tid; j2 < m2; j2 += nt) {
-        dst[j2] = (sm[swz(j2)] * cur).v;
-        cur = cur * step;
+        dst[j2] = p2f::fix(p2f::mm((double)sm[swz(j2)], cur));
+        cur = p2f::mm(cur, step);
     }
 }
 
@@ -320,6 +360,13 @@ hipError_t ntt_tables_create(NttTables *t) {
             uint32_t *dst = all.data() + off_scale + ((size_t)(mode * LDE_MAX_LOG + log_n) << 12);
             for (uint32_t q = 0; q < n2; q++) dst[q] = (ninv * Fp::raw(pw[(n2 - bitrev_host(q, log_n2)) & (n2 - 1)])).v;
         }
+    // canonical (centred, two's complement) copies of lde_tw and lde_scale: operands of the FP64 products
+    const size_t off_tw_c = all.size();
+    auto centred_word = [](uint32_t mont) -> uint32_t { uint32_t c = Fp::raw(mont).canonical(); return c > P / 2 ? c - P : c; };
+    for (size_t i = off_tw; i < off_scale; i++) all.push_back(centred_word(all[i]));
+    const size_t off_scale_c = all.size();
+    all.resize(off_scale_c + ((size_t)3 * LDE_MAX_LOG << 12));
+    for (size_t i = 0; i < ((size_t)3 * LDE_MAX_LOG << 12); i++) all[off_scale_c + i] = centred_word(all[off_scale + i]);
     uint32_t *d = nullptr;
     hipError_t e = hipMalloc(&d, all.size() * 4);
     if (e != hipSuccess) return e;
@@ -332,6 +379,8 @@ hipError_t ntt_tables_create(NttTables *t) {
     t->sh_lo = d + 8192 + 2048;
     t->lde_tw = d + off_tw;
     t->lde_scale = d + off_scale;
+    t->lde_tw_c = d + off_tw_c;
+    t->lde_scale_c = d + off_scale_c;
     return hipSuccess;
 }
 void ntt_tables_destroy(NttTables *t) {
