@@ -204,7 +204,7 @@ def main():
     shard_alg = 36 * ks["cells_main"] + 36 * ks["cells_perm"] + 28 * ks["cells_quotient"] + 24 * ks["cells_prep"]
     step_s = dt / args.steps / max(len(mine), 1)
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1b_pmc_k1_traffic.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1c_pmc_k1_traffic.json")))
     except OSError:
         pmc = {}
 
@@ -246,7 +246,7 @@ def main():
             "unit": "GB/s",
             "frac": lde_gbps / HBM_PEAK_GBPS,
             "traffic": pmc.get("k1_hbm_bytes_per_proof"),
-            "traffic_source": "profiles/r1b_pmc_k1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this command, "
+            "traffic_source": "profiles/r1c_pmc_k1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this command, "
                               "gfx950 FETCH_SIZE x2 correction applied where the guide prescribes it); bytes per proof, like alg_bytes_per_proof",
             "alg_bytes_per_proof": ks["lde_alg_bytes"],
             "ms_per_proof": ks["lde_ms"],

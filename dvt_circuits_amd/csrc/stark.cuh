@@ -56,6 +56,10 @@ struct ConstraintFolder {
     // pending first half of a LogUp batch
     T pend_m;
     Fp4 pend_d;
+    // T = Fp: the LogUp batch constraints (F_p^4 products of per-row values) are evaluated on canonical residues in
+    // doubles (Fd4, f64dot.cuh) and accumulated, already multiplied by their alpha power, in acc_c
+    Fd4 pend_dd, acc_c = {{0.0, 0.0, 0.0, 0.0}}, perm_alpha_c;
+    double pend_md = 0.0;
 
     DVT_HD ConstraintFolder(const Access &a) : ax(a), acc(Fp4::zero()) {}
     DVT_HD static T K(uint32_t monty) {
@@ -99,7 +103,49 @@ struct ConstraintFolder {
         else fold_t(idx, v * sel_trans);
     }
 
+    // (T = Fp) canonical d and signed multiplicity of an interaction, canonical permutation-trace value
+    DVT_HD Fd4 denominator_c(int bus, const T *vals, int n) const {
+        DotAcc4 s;
+        for (int k = 0; k < n; k++) {
+            if constexpr (BASE) s.add(beta_d + 4 * k, vals[k]);
+            if ((k & 31) == 31) s.reduce();
+        }
+        Fd4 d;
+        s.value_canonical(d.c);
+        for (int k = 0; k < 4; k++) d.c[k] += perm_alpha_c.c[k];
+        d.c[0] += (double)bus;
+        return d;
+    }
+    DVT_HD Fd4 perm_c(int e) const {
+        const Fp4 p = ax.perm(e, 0);
+        Fd4 r;
+        for (int k = 0; k < 4; k++) r.c[k] = centred_from_mont(p.c[k].v);
+        return r;
+    }
+    DVT_HD void fold_c(int idx, const Fd4 &v) {   // acc_c += alpha^idx * v
+        Fd4 a;
+        for (int k = 0; k < 4; k++) a.c[k] = alpha_d[4 * idx + k];
+        acc_c = acc_c + a * v;
+    }
     DVT_HD void interaction(int j, int bus, int sign, int /*scope*/, const T &mult, const T *vals, int n) {
+        if constexpr (BASE) {
+            const Fd4 d = denominator_c(bus, vals, n);
+            const double m0 = centred_from_mont(mult.v), m = sign > 0 ? m0 : -m0;
+            if ((j & 1) == 0) {
+                pend_md = m;
+                pend_dd = d;
+                if (j == Air::N_INTERACTIONS - 1) {  // odd tail: perm * d - m = 0
+                    Fd4 v = perm_c(j >> 1) * d;
+                    v.c[0] -= m;
+                    fold_c(Air::N_CONSTRAINTS + (j >> 1), v);
+                }
+            } else {
+                const Fd4 lhs = (perm_c(j >> 1) * pend_dd) * d;
+                const Fd4 rhs = d * pend_md + pend_dd * m;
+                fold_c(Air::N_CONSTRAINTS + (j >> 1), lhs - rhs);
+            }
+            return;
+        }
         Fp4 d = denominator(bus, vals, n);
         T m = sign > 0 ? mult : -mult;
         if ((j & 1) == 0) {
@@ -130,10 +176,17 @@ struct ConstraintFolder {
     }
 
     DVT_HD Fp4 run() {
+        if constexpr (BASE)
+            for (int k = 0; k < 4; k++) perm_alpha_c.c[k] = centred_from_mont(perm_alpha.c[k].v);
         Air::constraints(*this);
         Air::interactions(*this);
         finish_logup();
-        if constexpr (BASE) acc += acc_d.value();
+        if constexpr (BASE) {
+            acc += acc_d.value();
+            Fp4 lc;   // acc_c holds canonical residues: back to Montgomery words
+            for (int k = 0; k < 4; k++) lc.c[k] = Fp::raw(p2f::to_mont(acc_c.c[k]));
+            acc += lc;
+        }
         return acc;
     }
 };
