@@ -48,7 +48,7 @@ def test_world_size_2_gloo_barrier_max_and_sharding():
 
 def test_bench_line_fields_of_committed_profile():
     """the committed round-1 bench line carries every field of the contract"""
-    line = json.load(open(os.path.join(ROOT, "profiles", "r1b_bench_line.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r1c_bench_line.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in line, k
