@@ -36,18 +36,23 @@ static int die(const std::string &m) {
 int main(int argc, char **argv) {
     if (argc < 2) return die("usage: dvt_prover_host prove|execute|verify --type T -i FILE [-o FILE] [--show-report] [--elf FILE]");
     const std::string verb = argv[1];
-    std::string type, input, output, elf_path;
+    std::string type, input, output, elf_path, schema_path;
     bool show_report = false, auth = false;
     for (int i = 2; i < argc; i++) {
-        std::string a = argv[i];
-        auto next = [&]() -> std::string { return i + 1 < argc ? std::string(argv[++i]) : std::string(); };
+        std::string a = argv[i], inline_val;
+        bool has_inline = false;
+        if (a.rfind("--", 0) == 0) {   // --key=value, as the reference's test vectors write it (clap accepts both forms)
+            size_t eq = a.find('=');
+            if (eq != std::string::npos) { inline_val = a.substr(eq + 1); a = a.substr(0, eq); has_inline = true; }
+        }
+        auto next = [&]() -> std::string { return has_inline ? inline_val : (i + 1 < argc ? std::string(argv[++i]) : std::string()); };
         if (a == "--type") type = next();
         else if (a == "-i" || a == "--input-file") input = next();
         else if (a == "-o" || a == "--output-file-path") output = next();
         else if (a == "--elf") elf_path = next();
         else if (a == "--show-report") show_report = true;
         else if (a == "--auth-commitment") auth = true;  // the reference selects this at build time (cargo feature)
-        else if (a == "--json-schema-file") { next(); fprintf(stderr, "note: --json-schema-file is ignored (schema validation is product UI)\n"); }
+        else if (a == "--json-schema-file") schema_path = next();
         else return die("unknown argument " + a);
     }
     if (verb != "prove" && verb != "execute" && verb != "verify") return die("unknown sub-command " + verb);
@@ -60,6 +65,23 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> elf, in;
     if (!read_file(elf_path, &elf)) return die("cannot read ELF " + elf_path);
     if (!read_file(input, &in)) return die("cannot read " + input);
+
+    if (!schema_path.empty() && verb != "verify") {  // validate_if_needed (src/main.rs:509-541)
+        std::vector<uint8_t> sch;
+        if (!read_file(schema_path, &sch)) return die("Could not read schema file '" + schema_path + "'");
+        char *verr = nullptr;
+        if (dvt_json_schema_validate((const char *)sch.data(), sch.size(), (const char *)in.data(), in.size(), &verr)) {
+            std::string all = verr ? verr : "?";
+            size_t at = 0;
+            while (at <= all.size()) {
+                size_t e = all.find('\n', at);
+                fprintf(stderr, "Validation error in '%s': %s\n", input.c_str(), all.substr(at, e == std::string::npos ? std::string::npos : e - at).c_str());
+                if (e == std::string::npos) break;
+                at = e + 1;
+            }
+            return die("JSON validation failed for '" + input + "'");
+        }
+    }
 
     if (verb == "verify") {
         dvt_prover *p = nullptr;

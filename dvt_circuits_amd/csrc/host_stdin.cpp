@@ -15,7 +15,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <cmath>
 #include <memory>
+#include <regex>
 #include <string>
 #include <vector>
 
@@ -237,6 +239,88 @@ bool encode(const Schema &s, const JVal &v, bool auth, Cbor *c, std::string *err
     return true;
 }
 
+// ------------------------------------------------------------------ JSON-schema check (draft-07 subset)
+// What the reference does with --json-schema-file (src/main.rs:509-541: JSONSchema::compile + validate, every error
+// printed, then "JSON validation failed").  Keywords: exactly those of the reference's own schemas (spec/json/*.json,
+// generated from its Rust types): type, $ref into #/definitions, required, properties, items, minLength, maxLength,
+// pattern, minimum / maximum; annotations ($schema, title, description, format, definitions) are ignored, and so is any
+// other keyword, as the draft prescribes for unknown ones.
+struct SchemaCheck {
+    const JVal &root;
+    std::vector<std::string> errors;
+    const JVal *resolve(const JVal &sch, int depth) {
+        const JVal *cur = &sch;
+        while (cur && cur->kind == JVal::Obj && depth++ < 32) {
+            const JVal *ref = cur->get("$ref");
+            if (!ref || ref->kind != JVal::Str) return cur;
+            const std::string &r = ref->str;
+            if (r.rfind("#/", 0) != 0) { errors.push_back("unsupported $ref `" + r + "`"); return nullptr; }
+            const JVal *t = &root;
+            size_t at = 2;
+            while (t && at <= r.size()) {
+                size_t e = r.find('/', at);
+                std::string key = r.substr(at, e == std::string::npos ? std::string::npos : e - at);
+                t = t->kind == JVal::Obj ? t->get(key) : nullptr;
+                if (e == std::string::npos) break;
+                at = e + 1;
+            }
+            if (!t) { errors.push_back("unresolvable $ref `" + r + "`"); return nullptr; }
+            cur = t;
+        }
+        return cur;
+    }
+    static bool is_type(const JVal &v, const std::string &t) {
+        if (t == "object") return v.kind == JVal::Obj;
+        if (t == "array") return v.kind == JVal::Arr;
+        if (t == "string") return v.kind == JVal::Str;
+        if (t == "boolean") return v.kind == JVal::Bool;
+        if (t == "null") return v.kind == JVal::Null;
+        if (t == "number") return v.kind == JVal::Num;
+        if (t == "integer") return v.kind == JVal::Num && std::floor(v.num) == v.num;
+        return true;
+    }
+    void check(const JVal &sch0, const JVal &v, const std::string &at) {
+        const JVal *sch = resolve(sch0, 0);
+        if (!sch || sch->kind != JVal::Obj) return;
+        if (const JVal *t = sch->get("type")) {
+            bool ok = false;
+            if (t->kind == JVal::Str) ok = is_type(v, t->str);
+            else if (t->kind == JVal::Arr) for (auto &x : t->arr) ok = ok || (x.kind == JVal::Str && is_type(v, x.str));
+            else ok = true;
+            if (!ok) { errors.push_back(at + ": is not of type " + (t->kind == JVal::Str ? "\"" + t->str + "\"" : "in the list")); return; }
+        }
+        if (v.kind == JVal::Str) {
+            // (lengths count characters; the reference's strings are ASCII hex)
+            if (const JVal *m = sch->get("minLength")) if (m->kind == JVal::Num && v.str.size() < (size_t)m->num) errors.push_back(at + ": is shorter than " + std::to_string((long)m->num) + " characters");
+            if (const JVal *m = sch->get("maxLength")) if (m->kind == JVal::Num && v.str.size() > (size_t)m->num) errors.push_back(at + ": is longer than " + std::to_string((long)m->num) + " characters");
+            if (const JVal *m = sch->get("pattern"))
+                if (m->kind == JVal::Str) {
+                    try {
+                        if (!std::regex_search(v.str, std::regex(m->str, std::regex::ECMAScript))) errors.push_back(at + ": does not match \"" + m->str + "\"");
+                    } catch (const std::regex_error &) { errors.push_back(at + ": schema pattern \"" + m->str + "\" is not a valid regular expression"); }
+                }
+        }
+        if (v.kind == JVal::Num) {
+            if (const JVal *m = sch->get("minimum")) if (m->kind == JVal::Num && v.num < m->num) errors.push_back(at + ": is less than the minimum");
+            if (const JVal *m = sch->get("maximum")) if (m->kind == JVal::Num && v.num > m->num) errors.push_back(at + ": is greater than the maximum");
+        }
+        if (v.kind == JVal::Obj) {
+            if (const JVal *req = sch->get("required"))
+                if (req->kind == JVal::Arr)
+                    for (auto &k : req->arr)
+                        if (k.kind == JVal::Str && !v.get(k.str)) errors.push_back(at + ": \"" + k.str + "\" is a required property");
+            if (const JVal *props = sch->get("properties"))
+                if (props->kind == JVal::Obj)
+                    for (auto &kv : props->obj)
+                        if (const JVal *child = v.get(kv.first)) check(kv.second, *child, at + "." + kv.first);
+        }
+        if (v.kind == JVal::Arr)
+            if (const JVal *items = sch->get("items"))
+                if (items->kind == JVal::Obj)
+                    for (size_t i = 0; i < v.arr.size(); i++) check(*items, v.arr[i], at + "[" + std::to_string(i) + "]");
+    }
+};
+
 }  // namespace
 
 extern "C" int dvt_stdin_from_json(const char *type, const char *json, size_t json_len, int auth_commitment, uint8_t **out, size_t *out_len,
@@ -263,4 +347,25 @@ extern "C" int dvt_stdin_from_json(const char *type, const char *json, size_t js
     *out = buf;
     *out_len = 8 + n;
     return DVT_OK;
+}
+
+extern "C" int dvt_json_schema_validate(const char *schema, size_t schema_len, const char *json, size_t json_len, char **err_text) {
+    if (err_text) *err_text = nullptr;
+    auto bad = [&](const std::string &m) { if (err_text) *err_text = strdup(m.c_str()); return DVT_ERR_INPUT; };
+    if (!schema || !json) return bad("null argument");
+    JVal sch, doc;
+    {
+        JParser jp{schema, schema + schema_len, ""};
+        if (!jp.parse(&sch)) return bad("Invalid JSON schema: " + jp.err);
+    }
+    {
+        JParser jp{json, json + json_len, ""};
+        if (!jp.parse(&doc)) return bad("Invalid JSON data: " + jp.err);
+    }
+    SchemaCheck c{sch, {}};
+    c.check(sch, doc, "$");
+    if (c.errors.empty()) return DVT_OK;
+    std::string all;
+    for (auto &e : c.errors) all += (all.empty() ? "" : "\n") + e;
+    return bad(all);
 }

@@ -193,6 +193,11 @@ uint64_t dvt_debug_p2_f64_selfcheck(uint32_t n, uint32_t seed);
  * cargo feature of that name.  Host-only; *out via dvt_free. */
 int dvt_stdin_from_json(const char *type, const char *json, size_t json_len, int auth_commitment, uint8_t **out,
                         size_t *out_len, char **err_text);
+/* `--json-schema-file` of the reference's CLI (src/main.rs:509-541: JSONSchema::compile + validate): checks
+ * `json` against the draft-07 `schema` (the keyword subset of the schema files under the reference's spec/json/: type, $ref
+ * into #/definitions, required, properties, items, minLength, maxLength, pattern, minimum, maximum).
+ * DVT_OK, or DVT_ERR_INPUT with one violation per line in *err_text (dvt_free).  Host-only. */
+int dvt_json_schema_validate(const char *schema, size_t schema_len, const char *json, size_t json_len, char **err_text);
 
 /* test hook, host-only: the traces (canonical, column-major) the prover would commit for shard
  * `shard` (0-based position) of this run cut at 2^log_shard cycles (0 = default 21).  Layout of *blob

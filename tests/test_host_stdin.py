@@ -7,6 +7,7 @@ import json
 import os
 import struct
 import subprocess
+import sys
 
 import pytest
 
@@ -135,6 +136,97 @@ def test_cli_execute_contract(tmp_path):
     env = dict(os.environ, DVT_ELF_DIR=str(tmp_path))
     (tmp_path / "finalization.elf").write_bytes(guests.hint_sum())
     assert subprocess.run([CLI, "execute", "--type", "finalization", "-i", inp], env=env, capture_output=True).returncode == 0
+
+
+SCHEMA_FILES = {"finalization": "finalization_spec.json", "bad-share": "share_exchange_spec.json",
+           "bad-partial-key": "bad_partial_key_spec.json", "bad-encrypted-share": "bad_encrypted_partial_key_spec.json"}
+
+
+def schema_errors(schema: bytes, doc: bytes):
+    import ctypes as C
+
+    lib = capi.load()
+    lib.dvt_json_schema_validate.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p)]
+    err = C.c_char_p()
+    rc = lib.dvt_json_schema_validate(schema, len(schema), doc, len(doc), C.byref(err))
+    msg = err.value.decode() if err.value else ""
+    if err.value:
+        lib.dvt_free(C.cast(err, C.c_void_p))
+    return rc, msg.split("\n") if msg else []
+
+
+@pytest.mark.parametrize("typ,name,auth", CASES)
+def test_reference_inputs_satisfy_the_reference_schemas(typ, name, auth):
+    """--json-schema-file (src/main.rs:509-541) on the reference's own data: its inputs validate against its schemas
+    (tests/golden/spec_json = spec/json of the reference)"""
+    schema = open(os.path.join(GOLD, "spec_json", SCHEMA_FILES[typ]), "rb").read()
+    rc, errs = schema_errors(schema, open(os.path.join(GOLD, name), "rb").read())
+    assert rc == 0, errs
+
+
+def test_schema_violations_are_reported():
+    schema = open(os.path.join(GOLD, "spec_json", "finalization_spec.json"), "rb").read()
+    js = json.load(open(os.path.join(GOLD, "finalization_example.json")))
+
+    def errs(mutate):
+        d = json.loads(json.dumps(js))
+        mutate(d)
+        rc, e = schema_errors(schema, json.dumps(d).encode())
+        assert rc == capi.DVT_ERR_INPUT
+        return e
+
+    e = errs(lambda d: d.pop("settings"))
+    assert len(e) == 1 and '"settings" is a required property' in e[0]
+    e = errs(lambda d: d["settings"].__setitem__("n", "3"))
+    assert e == ['$.settings.n: is not of type "integer"']
+    e = errs(lambda d: d["settings"].__setitem__("k", -1))
+    assert e == ["$.settings.k: is less than the minimum"]
+    e = errs(lambda d: d["generations"][1].__setitem__("base_hash", d["generations"][1]["base_hash"][:-1] + "g"))
+    assert len(e) == 1 and e[0].startswith("$.generations[1].base_hash: does not match")
+    e = errs(lambda d: d.__setitem__("aggregate_pubkey", d["aggregate_pubkey"] + "00"))   # too long AND off-pattern: both reported
+    assert len(e) == 2 and all(x.startswith("$.aggregate_pubkey") for x in e)
+    e = errs(lambda d: d.__setitem__("generations", {}))
+    assert e == ['$.generations: is not of type "array"']
+    assert schema_errors(b"{ nope", b"{}")[0] == capi.DVT_ERR_INPUT and schema_errors(schema, b"[1,")[0] == capi.DVT_ERR_INPUT
+
+
+def test_vector_harness_and_cli_schema_flag(tmp_path):
+    """tools/run_vectors.py = the reference's script/run.sh: scenario -> scratch file, cmd_extra_args (with their
+    --key=value spelling and schema paths relative to the reference root), exit code against the expectation"""
+    meta = json.load(open(os.path.join(GOLD, "README_host_inputs.json")))
+    vec_dir, elf_dir, root = tmp_path / "vectors", tmp_path / "elf", tmp_path / "root"
+    for d in (vec_dir, elf_dir, root / "spec" / "json"):
+        d.mkdir(parents=True)
+    for f in os.listdir(os.path.join(GOLD, "spec_json")):
+        (root / "spec" / "json" / f).write_bytes(open(os.path.join(GOLD, "spec_json", f), "rb").read())
+    for name, m in meta.items():
+        if m["params"]:
+            (vec_dir / name).write_text(json.dumps({"scenario": json.load(open(os.path.join(GOLD, name))), "params": m["params"]}))
+    for typ in SCHEMA_FILES:                                   # stand-in guests: accept every input
+        (elf_dir / (typ + ".elf")).write_bytes(guests.hint_sum())
+    env = dict(os.environ, DVT_ELF_DIR=str(elf_dir))
+    run = lambda *extra: subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_vectors.py"), "--cwd", str(root), str(vec_dir), *extra],
+                                        env=env, capture_output=True, text=True)
+    r = run()
+    # the stand-in guests exit 0 on everything: vectors that expect 0 pass, vectors that expect the guest to reject fail
+    want_pass = sorted(n for n, m in meta.items() if m["params"] and m["params"]["expected_exit_code"] == 0)
+    want_fail = sorted(n for n, m in meta.items() if m["params"] and m["params"]["expected_exit_code"] == 1)
+    assert sorted(l.split("/")[-1] for l in r.stdout.splitlines() if l.startswith("[PASS]")) == want_pass, r.stdout
+    assert sorted(l.split("/")[-1].split(" ")[0] for l in r.stdout.splitlines() if l.startswith("[FAIL]")) == want_fail
+    assert r.returncode == 1 and f"passed {len(want_pass)}  failed {len(want_fail)}" in r.stdout
+    r = run("--filter", "share_no_auth")
+    assert r.returncode == 0 and "passed 1  failed 0  skipped 3" in r.stdout
+    # with guests that reject everything the expectations flip; a schema violation alone is exit code 1 as well
+    for typ in SCHEMA_FILES:
+        (elf_dir / (typ + ".elf")).write_bytes(guests.exit_with(1))
+    assert f"passed {len(want_fail)}  failed {len(want_pass)}" in run().stdout
+    bad = json.load(open(os.path.join(GOLD, "finalization_example.json")))
+    bad["settings"]["n"] = "three"
+    (tmp_path / "bad.json").write_text(json.dumps(bad))
+    (elf_dir / "finalization.elf").write_bytes(guests.hint_sum())
+    r = subprocess.run([CLI, "execute", "--type=finalization", "--json-schema-file=spec/json/finalization_spec.json", "-i", str(tmp_path / "bad.json")],
+                       cwd=root, env=env, capture_output=True, text=True)
+    assert r.returncode == 1 and "Validation error in" in r.stderr and "JSON validation failed" in r.stderr
 
 
 @pytest.mark.gpu
