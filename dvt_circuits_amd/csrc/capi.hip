@@ -21,6 +21,7 @@ struct dvt_prover {
     StarkConfig cfg;
     uint32_t log_shard = 21;          // cycles per shard = 2^log_shard (SP1's default shard size)
     uint64_t max_cycles = 1ull << 36;
+    bool keep_phase1 = true;          // keep K0 output, main LDEs and tree of phase 1 in HBM for phase 2 ("keep_phase1": 0 recomputes)
     std::string err;
     std::mutex mu;
 };
@@ -140,6 +141,7 @@ int dvt_prover_create(const char *cfg_json, dvt_prover **out) {
     p->cfg.pow_bits = (uint32_t)cfg_int(cfg_json, "pow_bits", 16);
     p->eng.profile = cfg_int(cfg_json, "profile", 0) != 0;
     p->log_shard = (uint32_t)cfg_int(cfg_json, "log_shard_size", 21);
+    p->keep_phase1 = cfg_int(cfg_json, "keep_phase1", 1) != 0;
     if (p->log_shard < 4 || p->log_shard > 22) { delete p; return fail(nullptr, DVT_ERR_INPUT, "log_shard_size must be 4..22"); }
     if (p->cfg.num_queries == 0 || p->cfg.num_queries > 1024 || p->cfg.pow_bits > 30) {
         delete p;
@@ -529,7 +531,7 @@ static int shard_commit(dvt_prover *p, const dvt_pk *pk, dvt_job *j, size_t i, u
     // keep the phase-1 results in HBM while they fit (about 3 GB per 2^21-cycle shard); otherwise phase 2 recomputes
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
-    MainCache *keep = (s.cache.tree || free_b > ((size_t)24 << 30)) ? &s.cache : nullptr;
+    MainCache *keep = p->keep_phase1 && (s.cache.tree || free_b > ((size_t)24 << 30)) ? &s.cache : nullptr;
     if (keep && !s.d_cpu) {
         bool ok = hipMalloc(&s.d_cpu, ((size_t)RV32_CPU_MAIN_W << s.log_n[RV32_CHIP_CPU]) * 4) == hipSuccess && hipMalloc(&s.d_byte, j->byte_words * 4) == hipSuccess &&
                   hipMalloc(&s.d_prog, j->prog_words * 4) == hipSuccess;

@@ -45,7 +45,9 @@ typedef struct dvt_pk dvt_pk;
 
 /* ---------------------------------------------------------------- lifecycle */
 /* ProverClient::from_env() (src/main.rs:438,461,481).  cfg_json may be NULL or
- * a JSON object: {"device":0,"fri_queries":100,"pow_bits":16,"profile":0}. */
+ * a JSON object: {"device":0,"fri_queries":100,"pow_bits":16,"profile":0,"log_shard_size":21,
+ * "keep_phase1":1}.  keep_phase1 = 0 makes phase 2 of a shard recompute K0 and the main-trace commitment
+ * instead of keeping them in HBM (about 3 GB per 2^21-cycle shard) between the two phases. */
 int dvt_prover_create(const char *cfg_json, dvt_prover **out);
 void dvt_prover_destroy(dvt_prover *p);
 /* last error text of this handle (or of the failed create when p == NULL) */

@@ -122,6 +122,27 @@ def test_multi_shard_proof(gpu):
     p.close()
 
 
+def test_phase2_recompute_path_gives_the_same_bytes(gpu):
+    """with "keep_phase1": 0 (what a GPU short of HBM falls back to) phase 2 regenerates the traces and the main
+    commitment of every shard: same proof, byte for byte"""
+    from dvt_circuits_amd import capi
+
+    elf, want = guests.bignum(3, limbs=12)
+    p = capi.Prover('{"fri_queries": %d, "pow_bits": %d, "log_shard_size": 10}' % (Q, POW))
+    pk, vk = p.setup(elf)
+    kept, _ = p.prove_core(pk)
+    p.pk_free(pk)
+    p.close()
+    p = capi.Prover('{"fri_queries": %d, "pow_bits": %d, "log_shard_size": 10, "keep_phase1": 0}' % (Q, POW))
+    pk, vk2 = p.setup(elf)
+    recomputed, _ = p.prove_core(pk)
+    assert vk2 == vk and recomputed == kept
+    ok, ec, pv, why = capi.verify(vk, recomputed, Q, POW)
+    assert ok and pv == want, why
+    p.pk_free(pk)
+    p.close()
+
+
 def test_error_classes(gpu):
     from dvt_circuits_amd import capi
 
