@@ -800,7 +800,6 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
     for (auto &i : idx) i = ch.sample_bits(hmax);
     const uint32_t *d_idx = upload_vec(idx);
     if (!d_idx) return false;
-    pf.queries.assign(nq, QueryProof());
     const uint32_t *trees_dev[4] = {pk.d_prep_digests, d_main_tree, d_perm_tree, d_quot_tree};
     const uint32_t trees_h[4] = {pk.prep_log_h, hmax, perm_hmax, hmax};
     // every gather writes into one device buffer; ONE download afterwards (50 small synchronous copies cost ~2 ms)
@@ -844,34 +843,35 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
         HIPCHK(launch_gather_siblings(stream, L.v, L.log_m, d_idx, nq, reinterpret_cast<Fp4 *>(d_q + layer_slot[l].rows_at)));
         HIPCHK(launch_gather_paths(stream, L.tree, L.log_m - 1, d_idx, nq, d_q + layer_slot[l].paths_at));
     }
+    // canonical words on the device, one download, then the query section of the proof straight in wire format
+    HIPCHK(launch_from_internal(stream, d_q, q_words));
     std::vector<uint32_t> hq(q_words);
     if (!download(hq.data(), d_q, q_words * 4)) return false;
-    for (int t = 0; t < 4; t++) {
-        if (tree_mats[t].empty()) continue;
-        const uint32_t *rows = hq.data() + tree_slot[t].rows_at, *paths = hq.data() + tree_slot[t].paths_at;
-        const uint32_t ncols = tree_ncols[t];
+    {
+        std::vector<uint32_t> &w = pf.query_words;
+        w.reserve(q_words + (size_t)nq * 64 + 16);
+        w.push_back(nq);
+        auto put = [&](const uint32_t *src, size_t n) { w.insert(w.end(), src, src + n); };
         for (uint32_t q = 0; q < nq; q++) {
-            TreeOpening &to = pf.queries[q].trees[t];
-            size_t at = (size_t)q * ncols;
-            for (auto &tmx : tree_mats[t]) {
-                std::vector<Fp> row(tmx.width);
-                for (uint32_t c = 0; c < tmx.width; c++) row[c] = Fp::raw(rows[at + c]);
-                at += tmx.width;
-                to.rows.push_back(std::move(row));
+            for (int t = 0; t < 4; t++) {
+                if (tree_mats[t].empty()) { w.push_back(0); w.push_back(0); continue; }   // no rows, empty path
+                w.push_back((uint32_t)tree_mats[t].size());
+                const uint32_t *row = hq.data() + tree_slot[t].rows_at + (size_t)q * tree_ncols[t];
+                for (auto &tmx : tree_mats[t]) {
+                    w.push_back(tmx.width);
+                    put(row, tmx.width);
+                    row += tmx.width;
+                }
+                w.push_back(trees_h[t]);
+                put(hq.data() + tree_slot[t].paths_at + (size_t)q * trees_h[t] * 8, (size_t)trees_h[t] * 8);
             }
-            to.path.resize(trees_h[t]);
-            for (uint32_t l = 0; l < trees_h[t]; l++) to.path[l] = digest_from_words(&paths[((size_t)q * trees_h[t] + l) * 8]);
-        }
-    }
-    for (size_t li = 0; li < layers.size(); li++) {
-        const uint32_t th = layers[li].log_m - 1;
-        const uint32_t *sib = hq.data() + layer_slot[li].rows_at, *paths = hq.data() + layer_slot[li].paths_at;
-        for (uint32_t q = 0; q < nq; q++) {
-            FriLayerOpening lo;
-            for (int k = 0; k < 4; k++) lo.sibling.c[k] = Fp::raw(sib[(size_t)q * 4 + k]);
-            lo.path.resize(th);
-            for (uint32_t l = 0; l < th; l++) lo.path[l] = digest_from_words(&paths[((size_t)q * th + l) * 8]);
-            pf.queries[q].layers.push_back(std::move(lo));
+            w.push_back((uint32_t)layers.size());
+            for (size_t li = 0; li < layers.size(); li++) {
+                const uint32_t th = layers[li].log_m - 1;
+                put(hq.data() + layer_slot[li].rows_at + (size_t)q * 4, 4);
+                w.push_back(th);
+                put(hq.data() + layer_slot[li].paths_at + (size_t)q * th * 8, (size_t)th * 8);
+            }
         }
     }
     times.fri = tm.stop();

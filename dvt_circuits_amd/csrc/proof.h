@@ -39,6 +39,10 @@ struct ShardProof {
     Fp4 final_poly;
     Fp pow_witness;
     std::vector<QueryProof> queries;
+    // the prover fills the query section directly in wire format (canonical words, exactly what write_shard_proof
+    // emits for `queries`, including the leading count) instead of building `queries`: one pass over the downloaded
+    // gather buffer, no per-query vectors.  Empty = serialise `queries`.
+    std::vector<uint32_t> query_words;
 };
 
 struct WordWriter {
@@ -77,6 +81,10 @@ inline void write_shard_proof(WordWriter &w, const ShardProof &p) {
         w.efs(c.perm_l); w.efs(c.perm_n); w.efs(c.quot);
     }
     w.dgs(p.fri_roots); w.ef(p.final_poly); w.fp(p.pow_witness);
+    if (!p.query_words.empty()) {
+        w.w.insert(w.w.end(), p.query_words.begin(), p.query_words.end());
+        return;
+    }
     w.u32((uint32_t)p.queries.size());
     for (auto &q : p.queries) {
         for (int t = 0; t < 4; t++) {

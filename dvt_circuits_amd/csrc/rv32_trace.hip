@@ -1,12 +1,12 @@
 // K0 — trace generation on the GPU.
 //
-// The host executor uploads one compact 48-byte record per retired instruction;
-// one thread expands one record into the 86 columns of the cpu chip (byte limbs,
+// The host executor uploads one compact 68-byte record per retired instruction;
+// one thread expands one record into the 104 columns of the cpu chip (byte limbs,
 // carries, comparator flags, product bytes, ...) and counts its table lookups in
 // the byte-table and program-table multiplicity columns.
 // Column-major output: the 64 lanes of a wave write 64 consecutive rows of a
 // column, so every store is a coalesced 256-B request.  HBM-write bound
-// (4 B x 86 columns per cycle against 48 B read).
+// (4 B x 104 columns per cycle against 68 B read).
 //
 // Lookup counting: a few table rows are extremely hot (the high limbs of the
 // timestamp differences are almost always (0,0); loop bodies hit the same dozen
@@ -16,6 +16,7 @@
 // atomic, and the cache is flushed once per workgroup.  A wave whose active lanes
 // all carry the same key adds its lane count with a single LDS atomic.
 #include "kernels.h"
+#include "poseidon2_f64.cuh"
 #include "rv32.h"
 
 namespace dvt {
@@ -33,7 +34,9 @@ struct DeviceSink {
     const uint32_t *prog_row;
     uint32_t *lds_keys, *lds_counts;
 
-    __device__ void put(int col, uint32_t v) { cpu[(size_t)col * n + row] = Fp::from_canonical(v).v; }
+    // canonical value -> Montgomery word on the FP64 pipe (6-operation exact product with 2^32 mod p instead of three
+    // quarter-rate integer multiplies; a row issues ~60 of these)
+    __device__ void put(int col, uint32_t v) { cpu[(size_t)col * n + row] = p2f::to_mont((double)v); }
     // (see rv32.h: keeps hipcc from re-associating the MUL carry chain)
     __device__ void fence(uint32_t &v) { asm volatile("" : "+v"(v)); }
 
