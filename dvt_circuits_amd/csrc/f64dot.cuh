@@ -46,29 +46,32 @@ struct DotAcc4 {
 // F_p^4 = F_p[x]/(x^4 - 11) on lazily reduced doubles (canonical residues, not Montgomery words).  A product reduces every
 // one of its 16 coefficient products (p2f::mm, 6 operations, |result| < 0.51 p), so its coefficients are bounded by
 // (1 + 3 * 11) * 0.51 p < 2^35.2 whatever the inputs (which must stay below 2^38 so that |a_i b_j| < 2^76); sums and
-// differences are plain adds.  Costs 108 full-rate operations against 16 Montgomery products (3 quarter-rate multiplies
+// differences are plain adds.  Costs 96 full-rate operations against 16 Montgomery products (3 quarter-rate multiplies
 // + 4 operations each) and 12 three-instruction modular additions.
 struct Fd4 {
     double c[4];
 };
 DVT_HD Fd4 operator*(const Fd4 &a, const Fd4 &b) {
-    using p2f::mm;
+    // every b_j takes part in four products: its quotient estimate b_j / p is computed once (p2f::mm_pre)
+    const double q0 = b.c[0] * p2f::PINV, q1 = b.c[1] * p2f::PINV, q2 = b.c[2] * p2f::PINV, q3 = b.c[3] * p2f::PINV;
+    auto m = [&](int i, int j, double qj) { return p2f::mm_pre(a.c[i], b.c[j], qj); };
     Fd4 r;
-    r.c[0] = fma(11.0, mm(a.c[1], b.c[3]) + mm(a.c[2], b.c[2]) + mm(a.c[3], b.c[1]), mm(a.c[0], b.c[0]));
-    r.c[1] = fma(11.0, mm(a.c[2], b.c[3]) + mm(a.c[3], b.c[2]), mm(a.c[0], b.c[1]) + mm(a.c[1], b.c[0]));
-    r.c[2] = fma(11.0, mm(a.c[3], b.c[3]), mm(a.c[0], b.c[2]) + mm(a.c[1], b.c[1]) + mm(a.c[2], b.c[0]));
-    r.c[3] = (mm(a.c[0], b.c[3]) + mm(a.c[1], b.c[2])) + (mm(a.c[2], b.c[1]) + mm(a.c[3], b.c[0]));
+    r.c[0] = fma(11.0, m(1, 3, q3) + m(2, 2, q2) + m(3, 1, q1), m(0, 0, q0));
+    r.c[1] = fma(11.0, m(2, 3, q3) + m(3, 2, q2), m(0, 1, q1) + m(1, 0, q0));
+    r.c[2] = fma(11.0, m(3, 3, q3), m(0, 2, q2) + m(1, 1, q1) + m(2, 0, q0));
+    r.c[3] = (m(0, 3, q3) + m(1, 2, q2)) + (m(2, 1, q1) + m(3, 0, q0));
     return r;
 }
 DVT_HD Fd4 operator*(const Fd4 &a, double b) {   // |b| < 2^38
+    const double bq = b * p2f::PINV;
     Fd4 r;
-    for (int k = 0; k < 4; k++) r.c[k] = p2f::mm(a.c[k], b);
+    for (int k = 0; k < 4; k++) r.c[k] = p2f::mm_pre(a.c[k], b, bq);
     return r;
 }
 DVT_HD Fd4 operator+(const Fd4 &a, const Fd4 &b) { Fd4 r; for (int k = 0; k < 4; k++) r.c[k] = a.c[k] + b.c[k]; return r; }
 DVT_HD Fd4 operator-(const Fd4 &a, const Fd4 &b) { Fd4 r; for (int k = 0; k < 4; k++) r.c[k] = a.c[k] - b.c[k]; return r; }
 
 // centred canonical residue of a Montgomery word, as a double
-DVT_HD double centred_from_mont(uint32_t m) { return p2f::mm((double)m, p2f::MONT_RINV); }
+DVT_HD double centred_from_mont(uint32_t m) { return p2f::from_mont(m); }
 
 }  // namespace dvt

@@ -59,16 +59,26 @@ DVT_DEV double mm_exact_const(double a, double c) {
 // |a| < 2^51  ->  the representative in [-p/2, p/2] (+- a rounding slack far below 1 for |a| < 2^48)
 DVT_DEV double red(double a) { return fma(-rnd(a * PINV), PD, a); }
 
-DVT_DEV double from_mont(uint32_t m) { return mm((double)m, MONT_RINV); }
 DVT_DEV double from_canonical(uint32_t c) { return (double)c; }
 // r in (-p, p) -> canonical word
 DVT_DEV uint32_t fix(double r) { return (uint32_t)(r < 0.0 ? r + PD : r); }
-DVT_DEV uint32_t to_mont(double x) { return fix(mm(x, MONT_R)); }      // |x| < 2^48
 DVT_DEV uint32_t to_canonical(double x) { return fix(red(x)); }       // |x| < 2^48
 
+// a * b mod p with bp = b / p (rounded) supplied: q = round(a * bp), then a b - q p = (a b - q (p - 1)) - q, where
+// q (p - 1) = 15 q * 2^27 is exact in a double and the FMA result (|r + q| < 2^42) is exact: 5 operations, no error
+// term.  Same bounds as mm.  Worth it where one bp serves several products (the S-box: 23 operations instead of 24).
+constexpr double P_MINUS_1 = 2013265920.0;
+DVT_DEV double mm_pre(double a, double b, double bp) {
+    const double q = rnd(a * bp);
+    return fma(a, b, -(q * P_MINUS_1)) - q;
+}
+DVT_DEV double from_mont(uint32_t m) { return mm_pre((double)m, MONT_RINV, MONT_RINV / PD); }
+DVT_DEV uint32_t to_mont(double x) { return fix(mm_pre(x, MONT_R, MONT_R / PD)); }      // |x| < 2^48
 DVT_DEV double sbox(double x) {  // |x| < 2^38
-    double x2 = mm(x, x), x3 = mm(x2, x), x4 = mm(x2, x2);
-    return mm(x3, x4);
+    const double xp = x * PINV;
+    const double x2 = mm_pre(x, x, xp), x3 = mm_pre(x2, x, xp);
+    const double x2p = x2 * PINV, x4 = mm_pre(x2, x2, x2p);
+    return mm_pre(x3, x4, x4 * PINV);
 }
 
 // max |s| = B  ->  <= 35 B
