@@ -122,6 +122,41 @@ def test_multi_shard_proof(gpu):
     p.close()
 
 
+def test_full_size_shard_on_the_reference_input():
+    """BASELINE configs[1] at full size: the reference's finalization example through its host encoding, one shard
+    of ~2^21 cycles, production parameters (100 queries, 16 PoW bits).  No CPU oracle at this size: the properties are
+    acceptance by the verifier with the public values the guest must commit, determinism, and rejection of a tampered word."""
+    import os
+
+    from dvt_circuits_amd import capi
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "finalization_example.json"), "rb") as f:
+        buf = capi.stdin_from_json("finalization", f.read())
+    elf, want = guests.finalization_like(904, buf)
+    p = capi.Prover("{}")
+    pk, vk = p.setup(elf)
+    proof, rep = p.prove_core(pk, [buf])
+    assert (1 << 21) - 4096 < rep["cycles"] <= 1 << 21
+    w = np.frombuffer(proof, np.uint32)
+    assert int(w[1]) == 1                                     # one shard
+    ok, ec, pv, why = capi.verify(vk, proof)
+    assert ok and ec == 0 and pv == want, why
+    assert p.prove_core(pk, [buf])[0] == proof
+    for pos in (len(w) // 3, len(w) // 2, len(w) - 5):
+        t = w.copy()
+        t[pos] = (int(t[pos]) + 1) % 2013265921
+        assert not capi.verify(vk, t.tobytes())[0]
+    # a different input of the same length changes the committed values, and the old proof's values no longer match it
+    other = bytearray(buf)
+    other[100] ^= 1
+    proof2, _ = p.prove_core(pk, [bytes(other)])
+    ok2, _, pv2, _ = capi.verify(vk, proof2)
+    assert ok2 and pv2 != pv and pv2 == guests.finalization_like(904, bytes(other))[1]
+    p.pk_free(pk)
+    p.close()
+
+
 def test_phase2_recompute_path_gives_the_same_bytes(gpu):
     """with "keep_phase1": 0 (what a GPU short of HBM falls back to) phase 2 regenerates the traces and the main
     commitment of every shard: same proof, byte for byte"""
