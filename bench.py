@@ -37,12 +37,33 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 
 
-def workload_stdin():
-    """the reference's own example input through the reference's host-side encoding"""
+def workload_stdin(participants=0):
+    """the reference's own example input (or, with --participants N, a synthetic N-participant one in the same format:
+    tools/gen_dkg_input.py) through the reference's host-side encoding"""
     from dvt_circuits_amd import capi
 
+    if participants:
+        from tools import gen_dkg_input
+
+        return capi.stdin_from_json("finalization", json.dumps(gen_dkg_input.finalization(participants, 2)).encode())
     with open(os.path.join(ROOT, "tests", "golden", "finalization_example.json"), "rb") as f:
         return capi.stdin_from_json("finalization", f.read())
+
+
+def fit_iters(stdin_buf, total_shards, iters=0):
+    """largest multiply-accumulate count whose execution still fits total_shards shards of 2^21 cycles"""
+    from dvt_circuits_amd import capi
+    from tests import guests
+
+    if iters:
+        return iters
+    iters = 907 * total_shards
+    while True:
+        cycles = capi.execute(guests.finalization_like(iters, stdin_buf)[0], [stdin_buf])[1]["cycles"]
+        over = cycles - (total_shards << 21)
+        if over <= 0:
+            return iters
+        iters -= over // 2300 + 1
 
 
 def cpu_baseline(small_iters, big_iters):
@@ -86,6 +107,8 @@ def main():
     ap.add_argument("--cpu-small", type=int, default=112)
     ap.add_argument("--cpu-big", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--participants", type=int, default=0, help="0 = the reference's finalization example (BASELINE configs[1]); N = synthetic "
+                    "N-participant input of the same format (tools/gen_dkg_input.py), e.g. 255")
     args = ap.parse_args()
 
     import torch
@@ -115,8 +138,8 @@ def main():
 
     # workload: one execution of (shards_per_gpu x world) shards of 2^21 cycles; rank r owns shards r, r+world, ...
     total_shards = args.shards_per_gpu * world
-    iters = args.iters if args.iters else 907 * total_shards - 3
-    stdin_buf = workload_stdin()
+    stdin_buf = workload_stdin(args.participants)
+    iters = fit_iters(stdin_buf, total_shards, args.iters)
     elf, want_pv = guests.finalization_like(iters, stdin_buf)
     prover = capi.Prover('{"device": %d, "fri_queries": 100, "pow_bits": 16, "log_shard_size": 21}' % local)
     pk, vk = prover.setup(elf)
@@ -189,7 +212,7 @@ def main():
 
     # kernel-family timing on a profiled handle (HIP events on the prover stream, same shard)
     prof = capi.Prover('{"device": %d, "fri_queries": 100, "pow_bits": 16, "profile": 1}' % local)
-    pelf, _ = guests.finalization_like(904, stdin_buf)           # one shard
+    pelf, _ = guests.finalization_like(fit_iters(stdin_buf, 1), stdin_buf)           # one shard
     ppk, _ = prof.setup(pelf)
     pjob, _ = prof.prepare(ppk, [stdin_buf])
     prof.prove_job(ppk, pjob, want_bytes=False)
@@ -222,11 +245,14 @@ def main():
         "dtype": "u32",
         "data": "synthetic",
         "config": {
-            "workload": "BASELINE configs[1]: examples/finalization_test.json (tests/golden/finalization_example.json) through the reference's "
+            "workload": ("synthetic %d-participant finalization input (tools/gen_dkg_input.py, reference format) through the reference's " % args.participants
+                         if args.participants else
+                         "BASELINE configs[1]: examples/finalization_test.json (tests/golden/finalization_example.json) through the reference's ") +
                         "JSON -> CBOR -> SP1Stdin encoding, proven by the finalization-shaped synthetic guest (tests/guests.py:finalization_like: "
                         "reads the buffer, 384-bit multiply-accumulate seeded by it), one shard of ~2^21 RV32IM cycles; the reference's own guest "
                         "ELF is prebuilt machine code and is not run",
             "stdin_bytes": len(stdin_buf),
+            "participants": args.participants or 3,
             "guest_cycles_per_proof": cycles,
             "shards_per_proof": n_shards,
             "shards_per_gpu": args.shards_per_gpu,

@@ -259,3 +259,31 @@ def test_cli_prove_then_verify(tmp_path):
     out = tmp_path / "neg.bin"
     r = subprocess.run([CLI, "prove", "--type", "finalization", "-i", str(inp), "-o", str(out)], env=env, capture_output=True, text=True)
     assert r.returncode == 1 and "Proof generation failed" in r.stderr and not out.exists()
+
+
+def test_commitment_hash_formula_and_synthetic_inputs():
+    """(1) KAT from the reference's own data: every base_hash of its finalization example is
+    SHA-256(gen_id || n || k || len || base_pubkeys) (crates/dkg/src/verification.rs:151-175);
+    (2) tools/gen_dkg_input.py builds n-participant inputs with that formula, which pass the reference's schema and the
+    host encoder, and whose encoded size follows SURVEY.md section 8(a1)'s model (about 170 KB at n = 255, k = 2)"""
+    import hashlib
+
+    from tools import gen_dkg_input
+
+    ex = json.load(open(os.path.join(GOLD, "finalization_example.json")))
+    st = ex["settings"]
+    for g in ex["generations"]:
+        h = hashlib.sha256(bytes.fromhex(st["gen_id"]) + bytes([st["n"], st["k"], len(g["base_pubkeys"])]) + b"".join(bytes.fromhex(p) for p in g["base_pubkeys"]))
+        assert h.hexdigest() == g["base_hash"].lower()
+    schema = open(os.path.join(GOLD, "spec_json", "finalization_spec.json"), "rb").read()
+    small = gen_dkg_input.finalization(3, 2)
+    assert gen_dkg_input.finalization(3, 2) == small and gen_dkg_input.finalization(3, 2, seed=7) != small
+    assert [g["base_hash"] for g in small["generations"]] == sorted(g["base_hash"] for g in small["generations"])
+    assert schema_errors(schema, json.dumps(small).encode())[0] == 0
+    rc, buf = c_encode("finalization", json.dumps(small).encode())
+    assert rc == 0 and abs(len(buf) - len(capi.stdin_from_json("finalization", open(os.path.join(GOLD, "finalization_example.json"), "rb").read()))) < 16
+    big = gen_dkg_input.finalization(255, 2)
+    assert schema_errors(schema, json.dumps(big).encode())[0] == 0
+    rc, buf = c_encode("finalization", json.dumps(big).encode())
+    assert rc == 0 and 160_000 < len(buf) < 185_000
+    assert buf[8:] == enc(SCHEMAS["finalization"], big, False)
