@@ -163,8 +163,12 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
             s.put(U + i, cin);
         }
     } else if (F(F_AND) | F(F_OR) | F(F_XOR)) {
+        // the four byte lookups go through shared slots (tools/airgen/rv32.py): operands copied to u[11+i], u[4+i], u[19+i]
         int op = F(F_AND) ? 0 : F(F_OR) ? 1 : 2;
-        for (int i = 0; i < 4; i++) s.byte(op, (B(b, i) << 8) | B(c, i));
+        for (int i = 0; i < 4; i++) {
+            s.put(U + 11 + i, B(a, i)); s.put(U + 4 + i, B(b, i)); s.put(U + 19 + i, B(c, i));
+            s.byte(op, (B(b, i) << 8) | B(c, i));
+        }
     } else if (F(F_SLT) | F(F_SLTU) | F(F_BEQ) | F(F_BNE) | F(F_BLT) | F(F_BGE) | F(F_BLTU) | F(F_BGEU)) {
         const uint32_t sg = F(F_SLT) | F(F_BLT) | F(F_BGE);
         uint32_t bb[4], cc[4];
@@ -177,11 +181,16 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
         int k = -1;
         for (int i = 3; i >= 0; i--) if (bb[i] != cc[i]) { k = i; break; }
         uint32_t bc = k >= 0 ? bb[k] : 0, ccv = k >= 0 ? cc[k] : 0;
+        // u[0..3] differing-byte flags, u[4] 1/(b_cmp - c_cmp), u[10] b_cmp, u[20] c_cmp, u[19] lt; signed: u[9] = c_3 with
+        // its top bit in u[21], u[24] = b_3 with its top bit in u[25] (shared lookup slots, tools/airgen/rv32.py)
         if (k >= 0) s.put(U + k, 1);
-        s.put(U + 4, bc); s.put(U + 5, ccv);
-        if (k >= 0) s.put(U + 6, inv(Fp::from_canonical(bc) - Fp::from_canonical(ccv)).canonical());
-        s.put(U + 7, bc < ccv);
-        s.put(U + 8, msb_b); s.put(U + 9, msb_c);
+        s.put(U + 10, bc); s.put(U + 20, ccv);
+        if (k >= 0) s.put(U + 4, inv(Fp::from_canonical(bc) - Fp::from_canonical(ccv)).canonical());
+        s.put(U + 19, bc < ccv);
+        if (sg) {
+            s.put(U + 24, B(b, 3)); s.put(U + 25, msb_b);
+            s.put(U + 9, B(c, 3)); s.put(U + 21, msb_c);
+        }
         s.byte(B_LTU - 1, (bc << 8) | ccv);
     } else if (F(F_MUL) | F(F_MULHU)) {
         // (carries are materialised before any lookup is issued: with the atomics interleaved into

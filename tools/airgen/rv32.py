@@ -168,14 +168,32 @@ def build_cpu():
         ch.assert_zero(F["is_sub"] * (a[i] + c[i] + cin - b[i] - 256 * cy[i]))
         ch.assert_zero(sel_addsub * (cy[i] * (cy[i] - 1)))
 
-    # AND / OR / XOR : four byte lookups
+    # ---- byte-table lookups of the mutually exclusive families share interactions ("slots").
+    # A slot is one interaction [OP, R, B, C] whose entries are affine: OP = sum of (table opcode x family selector),
+    # R / B / C = a union column (plus a constant x selector where a family needs a constant there), multiplicity = the
+    # sum of the selectors.  Families put their operands into the slot's columns (copying them from a / b / c where the
+    # operands live outside the union block); a column a family does not use is 0 on its rows, which is also what the
+    # table forces for the U16 entries [7, 0, v, 0].  The MUL family's seven carry checks provide the slots:
+    #   u[4..7]  : AND / OR / XOR byte i  (R = u[11+i] = a_i, B = u[4+i] = b_i, C = u[19+i] = c_i; not u[18], which the
+    #              timestamp range check of every row reads as the memory family's high limb)
+    #   u[8]     : the memory family's timestamp limb (below)
+    #   u[9]     : comparator, sign bit of c's top byte (R = u[21], B = u[9] = c_3)
+    #   u[10]    : comparator, the byte comparison itself (R = u[19] = lt, B = u[10] = b_cmp, C = u[20] = c_cmp)
+    x, mcy = U[0:4], U[4:11] + [Expr.const(0)]
+
+    # AND / OR / XOR : four byte lookups on copies of the operand bytes
     op_bit = B_AND * F["is_and"] + B_OR * F["is_or"] + B_XOR * F["is_xor"]
     for i in range(4):
-        ch.send("byte", [op_bit, a[i], b[i], c[i]], sel_bit)
+        ch.assert_zero(sel_bit * (U[11 + i] - a[i]))
+        ch.assert_zero(sel_bit * (U[4 + i] - b[i]))
+        ch.assert_zero(sel_bit * (U[19 + i] - c[i]))
+        ch.send("byte", [op_bit + B_U16 * sel_mul, U[11 + i], U[4 + i], U[19 + i]], sel_bit + sel_mul)
 
-    # comparator (SLT, SLTU, branches): u[0..3] differing-byte flags, u[4] b_cmp, u[5] c_cmp,
-    # u[6] 1/(b_cmp - c_cmp), u[7] lt, u[8] msb(b3), u[9] msb(c3)
-    df, b_cmp, c_cmp, inv_d, lt, msb_b, msb_c = U[0:4], U[4], U[5], U[6], U[7], U[8], U[9]
+    # comparator (SLT, SLTU, branches): u[0..3] differing-byte flags, u[4] 1/(b_cmp - c_cmp), u[10] b_cmp, u[20] c_cmp,
+    # u[19] lt, u[9] copy of c_3 and u[21] its top bit, u[24] copy of b_3 and u[25] its top bit (the slot of the
+    # sub-word loads' sign byte)
+    df, inv_d, b_cmp, c_cmp, lt = U[0:4], U[4], U[10], U[20], U[19]
+    c3c, msb_c, b3c, msb_b = U[9], U[21], U[24], U[25]
     bt = b[3] + 128 * sel_signed - 256 * msb_b       # top bytes with the sign bit flipped when signed
     ct = c[3] + 128 * sel_signed - 256 * msb_c
     bb = b[0:3] + [bt]
@@ -190,9 +208,11 @@ def build_cpu():
     ch.assert_zero(sel_cmp * ((b_cmp - c_cmp) * inv_d - any_df))
     ch.assert_zero((sel_cmp - sel_signed) * msb_b)
     ch.assert_zero((sel_cmp - sel_signed) * msb_c)
-    ch.send("byte", [B_LTU, lt, b_cmp, c_cmp], sel_cmp)
-    ch.send("byte", [B_MSB, msb_b, b[3], 0], sel_signed)
-    ch.send("byte", [B_MSB, msb_c, c[3], 0], sel_signed)
+    ch.assert_zero(sel_signed * (b3c - b[3]))
+    ch.assert_zero(sel_signed * (c3c - c[3]))
+    ch.send("byte", [B_LTU * sel_cmp + B_U16 * sel_mul, lt, b_cmp, c_cmp], sel_cmp + sel_mul)          # (MUL: carry 6 in u[10])
+    ch.send("byte", [B_MSB * sel_signed + B_U16 * sel_mul, msb_c, c3c, 0], sel_signed + sel_mul)        # (MUL: carry 5 in u[9])
+    # (the sign of b's top byte goes through the slot [MSB, u[25], u[24], 0] of the sub-word loads, below)
     sel_set = F["is_slt"] + F["is_sltu"]
     ch.assert_zero(sel_set * (a[0] - lt))
     for i in range(1, 4):
@@ -204,19 +224,13 @@ def build_cpu():
 
     # MUL / MULHU : the half of the 64-bit product that is NOT the result lives in u[0..3] (x), the result half is `a`
     # itself; u[4..10] = the carries out of bytes 0..6 (the carry out of byte 7 of a 64-bit product is the constant 0).
-    # Lookups are shared with other families wherever the tuple expressions coincide (the families are mutually
-    # exclusive, so one interaction with the sum of the selectors serves both): the range check of x is the adder
-    # family's range check of u[0..3], the range check of `a` is the common one, carry 4 shares the U16 slot of the
-    # memory family's timestamp limb in u[8].
-    x, mcy = U[0:4], U[4:11] + [Expr.const(0)]
+    # The range check of x is the adder family's range check of u[0..3], the range check of `a` is the common one,
+    # every carry check is one of the shared slots above.
     for k in range(8):
         terms = esum(b[i] * c[k - i] for i in range(4) if 0 <= k - i < 4)
         cin = mcy[k - 1] if k else Expr.const(0)
         pk = F["is_mul"] * a[k] + F["is_mulhu"] * x[k] if k < 4 else F["is_mul"] * x[k - 4] + F["is_mulhu"] * a[k - 4]
         ch.assert_zero(sel_mul * (terms + cin - 256 * mcy[k]) - pk)
-    for k in range(7):
-        if k != 4:
-            ch.send("byte", [B_U16, 0, mcy[k], 0], sel_mul)
 
     # LUI / AUIPC / JAL / JALR link : a := imm   (pc-relative constants are folded at decode time)
     sel_const = F["is_lui"] + F["is_jal"] + F["is_jalr"]
@@ -275,7 +289,7 @@ def build_cpu():
     ch.assert_zero(sel_half * (a[1] - o0 * mp[1] - o2 * mp[3]))
     ch.assert_zero(F["is_lb"] * (sb - a[0]))
     ch.assert_zero(F["is_lh"] * (sb - a[1]))
-    ch.send("byte", [B_MSB, sgn, sb, 0], sel_sext)
+    ch.send("byte", [B_MSB, sgn, sb, 0], sel_sext + sel_signed)         # (signed compares: u[24] = b_3, u[25] = its top bit)
     ch.assert_zero((F["is_lbu"] + F["is_lhu"]) * sgn)
     ch.assert_zero(sel_byte * (a[1] - 255 * sgn))
     for i in (2, 3):
