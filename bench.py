@@ -294,7 +294,7 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_small, args.cpu_big)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     prover.job_free(job)
     prover.pk_free(pk)
     prover.close()

@@ -530,7 +530,7 @@ static int shard_commit(dvt_prover *p, const dvt_pk *pk, dvt_job *j, size_t i, u
     ShardJob &s = j->shards[i];
     // keep the phase-1 results in HBM while they fit (about 3 GB per 2^21-cycle shard); otherwise phase 2 recomputes
     size_t free_b = 0, total_b = 0;
-    (void)hipMemGetInfo(&free_b, &total_b);
+    if (p->keep_phase1 && !s.cache.tree) (void)hipMemGetInfo(&free_b, &total_b);   // (only the first commit of a shard asks)
     MainCache *keep = p->keep_phase1 && (s.cache.tree || free_b > ((size_t)24 << 30)) ? &s.cache : nullptr;
     if (keep && !s.d_cpu) {
         bool ok = hipMalloc(&s.d_cpu, ((size_t)RV32_CPU_MAIN_W << s.log_n[RV32_CHIP_CPU]) * 4) == hipSuccess && hipMalloc(&s.d_byte, j->byte_words * 4) == hipSuccess &&
