@@ -85,12 +85,14 @@ DVT_DEV double sbox(double x) {  // |x| < 2^38
 DVT_DEV void external_layer(double s[16]) {
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        double x0 = s[4 * c], x1 = s[4 * c + 1], x2 = s[4 * c + 2], x3 = s[4 * c + 3];
-        double t = (x0 + x1) + (x2 + x3);
-        s[4 * c + 0] = fma(2.0, x1, t + x0);
-        s[4 * c + 1] = fma(2.0, x2, t + x1);
-        s[4 * c + 2] = fma(2.0, x3, t + x2);
-        s[4 * c + 3] = fma(2.0, x0, t + x3);
+        // circ(2,3,1,1) in 9 operations: y0 = 2x0+3x1+x2+x3, y1 = x0+2x1+3x2+x3, y2 = x0+x1+2x2+3x3, y3 = 3x0+x1+x2+2x3
+        const double x0 = s[4 * c], x1 = s[4 * c + 1], x2 = s[4 * c + 2], x3 = s[4 * c + 3];
+        const double t01 = x0 + x1, t23 = x2 + x3, t = t01 + t23;
+        const double u = t + x1, v = t + x3;          // x0+2x1+x2+x3,  x0+x1+x2+2x3
+        s[4 * c + 0] = u + t01;
+        s[4 * c + 1] = fma(2.0, x2, u);
+        s[4 * c + 2] = v + t23;
+        s[4 * c + 3] = fma(2.0, x0, v);
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
