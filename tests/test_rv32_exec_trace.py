@@ -1,6 +1,7 @@
 """CPU tests (no GPU): the product's RV32IM executor and host trace generation,
 validated by (a) expected guest outputs computed in Python and (b) the oracle's
 generated constraint checker and exact LogUp multiset over the produced traces."""
+import os
 import struct
 
 import numpy as np
@@ -179,3 +180,63 @@ def test_every_muldiv_witness_cell_is_pinned(air):
     # (and the "inverse" of a zero divisor)
     want = {(r, n) for r in (0, 1) for n in ("cinv", "eb", "dcy")} | {(6, "eb"), (6, "cinv")} | {(7, "dcy")}
     assert free == want, sorted(free ^ want, key=str)
+
+
+def test_cpu_chip_witness_cells_are_pinned_per_family(air):
+    """Soundness regression for the cpu chip's shared lookup slots and derived flags (an original AIR: nothing in the
+    reference to compare with).  For one row of every instruction family in the `arith` guest, every single-cell change
+    must break a constraint or the LogUp balance, except in cells the family does not use: union-block columns outside
+    its layout and the operand / timestamp columns of a register port it does not drive.  The columns a family shares
+    a lookup slot through must be pinned on its rows."""
+    import re
+
+    P = 2013265921
+    names = {}
+    for line in open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dvt_circuits_amd", "csrc", "gen", "rv32_cols.h")):
+        m = re.match(r"#define RV32_CPU_(\w+) (\d+)", line)
+        if m and m.group(1) not in ("MAIN_W", "PREP_W"):
+            names[int(m.group(2))] = m.group(1)
+    col = {n: i for i, n in names.items()}
+    elf, _ = guests.arith()
+    chips, pubs, _ = capi.rv32_debug_traces(elf)
+    pv = capi.execute(elf)[2]
+    extra = [(5, [k] + list(pv[4 * k:4 * k + 4]), -1, 1) for k in range(len(pv) // 4)]
+    cpu = next(c for c in chips if air.chip(c["chip_id"]).name == b"cpu")
+    main = cpu["main"]
+    fam_cols = [i for i, n in names.items() if n.startswith("is_")]
+    free, seen = {}, set()
+    for row in range(main.shape[1]):
+        fam = [names[i] for i in fam_cols if main[i, row] == 1]
+        if not fam:
+            break
+        key = (fam[0], int(main[col["imm_c"], row]))
+        if key in seen:
+            continue
+        seen.add(key)
+        free[key] = set()
+        for c in range(main.shape[0]):
+            m = main.copy()
+            m[c, row] = (int(m[c, row]) + 1) % P
+            if air.check_constraints(cpu["chip_id"], m, cpu["prep"], pubs)[0]:
+                continue
+            if air.logup_unbalanced([dict(cpu, main=m) if ch is cpu else ch for ch in chips], pubs, extra=extra)[0]:
+                continue
+            free[key].add(names[c])
+    assert len(free) >= 25, sorted(free)
+    may_be_free = re.compile(r"^(u_\d+|[abc]_\d|p[abc]_(lo|sh|ts|same)|pa_prev_\d)$")
+    for key, cells in free.items():
+        bad = sorted(c for c in cells if not may_be_free.match(c))
+        assert not bad, f"{key}: unconstrained cells outside the union block / idle ports: {bad}"
+    u = lambda *idx: {f"u_{i}" for i in idx}
+    for key, cells in free.items():
+        fam = key[0]
+        if fam in ("is_mul", "is_mulhu"):            # product half, carries, and the zeros the shared U16 slots force
+            assert not cells & u(*range(0, 15), 18, 19, 20, 21, 22), (key, cells)
+        if fam in ("is_and", "is_or", "is_xor"):     # operand copies of the four shared slots
+            assert not cells & u(4, 5, 6, 7, 11, 12, 13, 14, 18, 19, 20, 21, 22), (key, cells)
+        if fam in ("is_slt", "is_blt", "is_bge"):    # signed compare: byte comparison + both sign lookups
+            assert not cells & u(0, 1, 2, 3, 9, 10, 18, 19, 20, 21, 24, 25), (key, cells)
+        if fam in ("is_lw", "is_sw"):                # the memory family fills the block up to the sub-word sign columns
+            assert not cells & u(*range(0, 24)), (key, cells)
+        if fam in ("is_add", "is_sub"):
+            assert not cells & u(0, 1, 2, 3, 18) and not cells & {"a_0", "a_1", "a_2", "a_3", "b_0", "b_3"}, (key, cells)
