@@ -80,9 +80,14 @@ def load():
     lib.dvt_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.dvt_setup.argtypes = [vp, C.c_char_p, sz, C.POINTER(vp), C.POINTER(u8p), C.POINTER(sz)]
     lib.dvt_execute.argtypes = [C.c_char_p, sz, C.POINTER(Buf), sz, C.c_uint64, C.POINTER(u8p), C.POINTER(sz), C.POINTER(Report), C.POINTER(C.c_char_p)]
+    lib.dvt_execute_io.argtypes = [C.c_char_p, sz, C.POINTER(Buf), sz, C.c_uint64, C.POINTER(u8p), C.POINTER(sz), C.POINTER(u8p), C.POINTER(sz), C.POINTER(Report), C.POINTER(C.c_char_p)]
     lib.dvt_prove_core.argtypes = [vp, vp, C.POINTER(Buf), sz, C.POINTER(u8p), C.POINTER(sz), C.POINTER(Report)]
     lib.dvt_verify.argtypes = [C.c_char_p, sz, C.c_char_p, sz, u32, u32, C.POINTER(C.c_int32), C.POINTER(u8p), C.POINTER(sz), C.POINTER(C.c_char_p)]
     lib.dvt_rv32_prepare.argtypes = [vp, vp, C.POINTER(Buf), sz, C.POINTER(vp), C.POINTER(Report)]
+    lib.dvt_rv32_prepare_part.argtypes = [vp, vp, C.POINTER(Buf), sz, sz, sz, C.POINTER(vp), C.POINTER(Report)]
+    lib.dvt_rv32_header_words.restype = u32
+    lib.dvt_rv32_job_exec_wait_seconds.argtypes = [vp]
+    lib.dvt_rv32_job_exec_wait_seconds.restype = C.c_double
     lib.dvt_rv32_prove_job.argtypes = [vp, vp, vp, C.POINTER(u8p), C.POINTER(sz)]
     lib.dvt_job_free.argtypes = [vp, vp]
     lib.dvt_job_free.restype = None
@@ -130,6 +135,19 @@ def execute(elf: bytes, stdin=(), max_cycles=0):
     if pv:
         lib.dvt_free(C.cast(pv, C.c_void_p))
     return rc, dict(cycles=rep.cycles, exit_code=rep.exit_code, halted=bool(rep.halted), unprovable=bool(rep.unprovable)), out, _take_str(lib, err)
+
+
+def execute_io(elf: bytes, stdin=(), max_cycles=0):
+    """execute() that also returns what the guest wrote to fds other than 3: (rc, report, public_values, stdout, error text)."""
+    lib = load()
+    pv, n, so, m, rep, err = u8p(), C.c_size_t(), u8p(), C.c_size_t(), Report(), C.c_char_p()
+    rc = lib.dvt_execute_io(elf, len(elf), _bufs(stdin), len(stdin), max_cycles, C.byref(pv), C.byref(n), C.byref(so), C.byref(m), C.byref(rep), C.byref(err))
+    out = C.string_at(pv, n.value) if pv else b""
+    sout = C.string_at(so, m.value) if so else b""
+    for ptr in (pv, so):
+        if ptr:
+            lib.dvt_free(C.cast(ptr, C.c_void_p))
+    return rc, dict(cycles=rep.cycles, exit_code=rep.exit_code, halted=bool(rep.halted), unprovable=bool(rep.unprovable)), out, sout, _take_str(lib, err)
 
 
 def stdin_from_json(circuit_type: str, json_bytes: bytes, auth_commitment=False) -> bytes:
@@ -190,10 +208,13 @@ def rv32_debug_traces(elf: bytes, stdin=(), log_shard=0, shard=0):
     return chips, pubs, ns.value
 
 
+HEADER_WORDS = 13   # main-trace Merkle root (8) + public values (5): dvt_rv32_header_words()
+
+
 def rv32_challenges(vk: bytes, headers):
-    """Host-only: the LogUp challenges common to all shards, from their 15-word headers (in shard order)."""
+    """Host-only: the LogUp challenges common to all shards, from their 13-word headers (in shard order)."""
     lib = load()
-    h = np.ascontiguousarray(headers, dtype=np.uint32).reshape(-1, 15)
+    h = np.ascontiguousarray(headers, dtype=np.uint32).reshape(-1, HEADER_WORDS)
     out = np.zeros(8, np.uint32)
     rc = lib.dvt_rv32_challenges(vk, len(vk), h.ctypes.data_as(u32p), h.shape[0], out.ctypes.data_as(u32p))
     if rc:
@@ -327,11 +348,16 @@ class Prover:
         self.lib.dvt_free(C.cast(out, C.c_void_p))
         return b, dict(cycles=rep.cycles, exit_code=rep.exit_code, halted=bool(rep.halted))
 
-    def prepare(self, pk, stdin=()):
-        """host execution + upload; returns (job handle, report)"""
+    def prepare(self, pk, stdin=(), first=0, stride=1):
+        """the executor pipeline (fast pass, traced re-execution of the owned shards first, first + stride, ...,
+        upload, phase 1 on the GPU); returns (job handle, report)"""
         job, rep = C.c_void_p(), Report()
-        self.check(self.lib.dvt_rv32_prepare(self.h, pk, _bufs(stdin), len(stdin), C.byref(job), C.byref(rep)))
+        self.check(self.lib.dvt_rv32_prepare_part(self.h, pk, _bufs(stdin), len(stdin), first, stride, C.byref(job), C.byref(rep)))
         return job, dict(cycles=rep.cycles, exit_code=rep.exit_code, halted=bool(rep.halted))
+
+    def job_exec_wait(self, job):
+        """seconds the GPU-side thread of that prepare waited for the host executor"""
+        return float(self.lib.dvt_rv32_job_exec_wait_seconds(job))
 
     def prove_job(self, pk, job, want_bytes=True):
         """K0..K9 on a prepared, HBM-resident shard"""
@@ -357,7 +383,7 @@ class Prover:
         return int(self.lib.dvt_rv32_job_shards(job))
 
     def commit_shard(self, pk, job, shard):
-        h = np.zeros(15, np.uint32)
+        h = np.zeros(HEADER_WORDS, np.uint32)
         self.check(self.lib.dvt_rv32_commit_shard(self.h, pk, job, shard, h.ctypes.data_as(u32p)))
         return h
 

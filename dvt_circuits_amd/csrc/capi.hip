@@ -3,16 +3,22 @@
 // computes returns DVT_ERR_DEVICE.  (dvt_machine_verify is host-only by nature.)
 #include "../../include/dvt_prover.h"
 
+#include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 
 #include "engine.h"
 #include "poseidon2_f64.cuh"
 #include "rv32.h"
+#include "sha256.h"
 
 using namespace dvt;
 
@@ -22,6 +28,9 @@ struct dvt_prover {
     uint32_t log_shard = 21;          // cycles per shard = 2^log_shard (SP1's default shard size)
     uint64_t max_cycles = 1ull << 36;
     bool keep_phase1 = true;          // keep K0 output, main LDEs and tree of phase 1 in HBM for phase 2 ("keep_phase1": 0 recomputes)
+    uint32_t exec_threads = 0;        // trace-mode executor threads of the prove pipeline ("exec_threads", 0 = from the host's core count)
+    hipStream_t copy_stream = nullptr;            // record uploads overlap the previous shard's kernels
+    std::vector<rv32::CycleRec *> pinned;         // pinned staging buffers of 2^log_shard records each, reused across calls
     std::string err;
     std::mutex mu;
 };
@@ -119,7 +128,7 @@ static bool vk_parse(const uint8_t *b, size_t len, VerifyingKey *vk) {
 
 extern "C" {
 
-uint32_t dvt_abi_version(void) { return 2; }
+uint32_t dvt_abi_version(void) { return 3; }
 
 int dvt_prover_create(const char *cfg_json, dvt_prover **out) {
     if (!out) return fail(nullptr, DVT_ERR_INPUT, "out == NULL");
@@ -142,12 +151,14 @@ int dvt_prover_create(const char *cfg_json, dvt_prover **out) {
     p->eng.profile = cfg_int(cfg_json, "profile", 0) != 0;
     p->log_shard = (uint32_t)cfg_int(cfg_json, "log_shard_size", 21);
     p->keep_phase1 = cfg_int(cfg_json, "keep_phase1", 1) != 0;
+    p->exec_threads = (uint32_t)std::max(0, cfg_int(cfg_json, "exec_threads", 0));
     if (p->log_shard < 4 || p->log_shard > 22) { delete p; return fail(nullptr, DVT_ERR_INPUT, "log_shard_size must be 4..22"); }
     if (p->cfg.num_queries == 0 || p->cfg.num_queries > 1024 || p->cfg.pow_bits > 30) {
         delete p;
         return fail(nullptr, DVT_ERR_INPUT, "fri_queries must be 1..1024 and pow_bits <= 30");
     }
     e = p->eng.init(dev);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         fail(nullptr, DVT_ERR_DEVICE, "handle setup: %s", hipGetErrorString(e));
         dvt_prover_destroy(p);
@@ -159,6 +170,9 @@ int dvt_prover_create(const char *cfg_json, dvt_prover **out) {
 
 void dvt_prover_destroy(dvt_prover *p) {
     if (!p) return;
+    (void)hipSetDevice(p->eng.device);
+    if (p->copy_stream) { (void)hipStreamSynchronize(p->copy_stream); (void)hipStreamDestroy(p->copy_stream); }
+    for (auto b : p->pinned) (void)hipHostFree(b);
     p->eng.shutdown();
     delete p;
 }
@@ -375,22 +389,16 @@ int dvt_last_stage_ms(dvt_prover *p, float out[6]) {
 
 // ====================================================================== rv32 boundary
 namespace {
-constexpr uint32_t CORE_PROOF_MAGIC = 0x32435644u;  // "DVC2"
-constexpr uint32_t N_PUB = rv32::N_PUBLIC;           // start_pc, next_pc, exit_code, shard, is_last, pv_start, pv_end
+constexpr uint32_t CORE_PROOF_MAGIC = 0x33435644u;  // "DVC3"
+constexpr uint32_t N_PUB = rv32::N_PUBLIC;           // start_pc, next_pc, exit_code, shard, is_last
 constexpr uint32_t HEADER_WORDS = 8 + N_PUB;         // per-shard commitment header: main root + public values (canonical)
+constexpr uint32_t PV_BUS = 5;                       // tools/airgen/rv32.py BUSES["pv"]
 
 std::vector<std::vector<uint8_t>> collect_stdin(const dvt_buf *bufs, size_t n) {
     std::vector<std::vector<uint8_t>> v(n);
     for (size_t i = 0; i < n; i++)
         if (bufs[i].len) v[i].assign(bufs[i].data, bufs[i].data + bufs[i].len);
     return v;
-}
-void fill_report(dvt_report *rep, const rv32::ExecResult &r) {
-    if (!rep) return;
-    rep->cycles = r.cycles;
-    rep->exit_code = r.halted ? r.exit_code : -1;
-    rep->halted = r.halted;
-    rep->unprovable = r.unsupported;
 }
 uint8_t *dup_bytes(const std::vector<uint8_t> &v, size_t *len) {
     uint8_t *b = (uint8_t *)malloc(v.size() + 1);
@@ -414,12 +422,19 @@ PermChallenges global_challenges(const VerifyingKey &vk, const uint32_t *headers
     c.beta = g.sample_ext();
     return c;
 }
+// SP1's committed-value digest: word k = little-endian u32 of bytes 4k..4k+3 of SHA-256(public-value bytes)
+// (an empty stream commits 42c4b0e3 141cfc98 ... = sha256("") read as LE words)
+void pv_digest_words(const std::vector<uint8_t> &pv, uint32_t out[8]) {
+    uint8_t dg[32];
+    sha256(pv.data(), pv.size(), dg);
+    for (int k = 0; k < 8; k++) out[k] = dg[4 * k] | (dg[4 * k + 1] << 8) | (dg[4 * k + 2] << 16) | ((uint32_t)dg[4 * k + 3] << 24);
+}
 }  // namespace
 
 struct ShardJob {
-    uint32_t index = 0;
+    uint32_t index = 0;       // shard number (1-based) = position in the execution + 1
     size_t n_recs = 0;
-    uint32_t pv_end = 0;
+    uint32_t next_pc = 0;
     rv32::CycleRec *d_recs = nullptr;
     uint32_t log_n[rv32::N_CHIPS] = {};
     bool present[rv32::N_CHIPS] = {};
@@ -430,13 +445,22 @@ struct ShardJob {
     // job's working buffers are used and phase 2 runs K0 again
     uint32_t *d_cpu = nullptr, *d_byte = nullptr, *d_prog = nullptr;
     bool traces_valid = false;
+    uint32_t header[HEADER_WORDS] = {};
+    bool header_valid = false;   // phase 1 ran (inside the prepare pipeline, or by commit_shard) and no phase 2 has consumed it
 };
-// one prepared execution: executor output cut into shards, resident in HBM, ready for K0..K9
+// one prepared execution: cut into shards by the executor; the shards this job owns (first, first + stride, ...) are
+// resident in HBM, ready for K0..K9
 struct dvt_job {
-    rv32::ExecResult res;  // per-cycle records are released after the upload
+    int exit_code = -1;
+    uint64_t cycles = 0;
+    std::vector<uint8_t> public_values;
+    size_t n_total = 0, first = 0, stride = 1;   // shards of the execution / which of them this job holds
     std::vector<ShardJob> shards;
     uint32_t *d_cpu = nullptr, *d_byte = nullptr, *d_prog = nullptr;  // working buffers (largest shard)
+    uint32_t work_log_cpu = 0;
     size_t byte_words = 0, prog_words = 0;
+    double t_exec_wait = 0;   // seconds the GPU thread spent waiting for the executor inside prepare
+    ShardJob *at(size_t pos) { return pos >= first && (pos - first) % stride == 0 && (pos - first) / stride < shards.size() ? &shards[(pos - first) / stride] : nullptr; }
 };
 
 static void job_release(dvt_job *j) {
@@ -453,65 +477,24 @@ static void job_release(dvt_job *j) {
     delete j;
 }
 
-// execute + auxiliary traces + upload (no lock: callers hold p->mu)
-static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_bufs, size_t nbuf, dvt_job **out, dvt_report *report) {
-    HIP_TRY(p, hipSetDevice(p->eng.device));
-    dvt_job *j = new dvt_job();
-    rv32::execute(pk->prog, collect_stdin(stdin_bufs, nbuf), true, p->max_cycles, p->log_shard, &j->res);
-    fill_report(report, j->res);
-    int rc = DVT_OK;
-    if (!j->res.error.empty()) rc = fail(p, DVT_ERR_GUEST, "guest trapped: %s", j->res.error.c_str());
-    else if (j->res.exit_code != 0) rc = fail(p, DVT_ERR_GUEST, "guest halted with exit code %d", j->res.exit_code);
-    else if (j->res.unsupported) rc = fail(p, DVT_ERR_UNSUPPORTED, "no chip for %s", j->res.unsupported_what.c_str());
-    if (rc) { job_release(j); return rc; }
-    const MachineDesc *m = machine_rv32();
-    uint32_t max_log_cpu = 0;
-    bool ok = true;
-    for (size_t si = 0; ok && si < j->res.shards.size(); si++) {
-        rv32::HostTraces T;
-        std::string err;
-        if (!rv32::build_aux_host(pk->prog, j->res, si, pk->prep, &T, &err)) { job_release(j); return fail(p, DVT_ERR_UNSUPPORTED, "%s", err.c_str()); }
-        ShardJob s;
-        auto &recs = j->res.shards[si].recs;
-        s.index = j->res.shards[si].index;
-        s.n_recs = recs.size();
-        s.pv_end = j->res.shards[si].pv_end;
-        for (int c = 0; c < m->n_chips; c++) { s.log_n[c] = T.log_n[c]; s.present[c] = T.present[c]; }
-        max_log_cpu = std::max(max_log_cpu, s.log_n[RV32_CHIP_CPU]);
-        ok = hipMalloc(&s.d_recs, s.n_recs * sizeof(rv32::CycleRec)) == hipSuccess &&
-             hipMemcpy(s.d_recs, recs.data(), s.n_recs * sizeof(rv32::CycleRec), hipMemcpyHostToDevice) == hipSuccess;
-        for (int c = 0; ok && c < m->n_chips; c++) {
-            if (c == RV32_CHIP_CPU || !s.present[c]) continue;
-            size_t words = T.main[c].size();
-            ok = hipMalloc(&s.d_aux[c], words * 4) == hipSuccess && hipMemcpy(s.d_aux[c], T.main[c].data(), words * 4, hipMemcpyHostToDevice) == hipSuccess;
-            // byte / program multiplicities stay plain integers until K0 has added the cpu rows' lookups
-            if (ok && c != RV32_CHIP_BYTE && c != RV32_CHIP_PROGRAM) ok = launch_to_internal(p->eng.stream, s.d_aux[c], words) == hipSuccess;
-        }
-        for (auto x : T.pubs) s.pubs.push_back(Fp::from_canonical(x));
-        std::vector<rv32::CycleRec>().swap(recs);
-        j->shards.push_back(std::move(s));
-    }
-    j->byte_words = (size_t)rv32::N_BYTE_OPS * 65536;
-    j->prog_words = (size_t)1 << pk->prep.log_n[RV32_CHIP_PROGRAM];
-    if (ok) ok = hipMalloc(&j->d_cpu, ((size_t)RV32_CPU_MAIN_W << max_log_cpu) * 4) == hipSuccess &&
-                 hipMalloc(&j->d_byte, j->byte_words * 4) == hipSuccess && hipMalloc(&j->d_prog, j->prog_words * 4) == hipSuccess;
-    if (ok) ok = hipStreamSynchronize(p->eng.stream) == hipSuccess;
-    if (!ok) { job_release(j); return fail(p, DVT_ERR_DEVICE, "uploading the shards to the device failed"); }
-    *out = j;
-    return DVT_OK;
-}
-
-// K0 of shard i (into the shard's own buffers when it has them, else the job's working buffers); fills the chip
+// K0 of a shard (into the shard's own buffers when it has them, else the job's working buffers); fills the chip
 // trace list of that shard.  `reuse`: phase 2 takes the traces phase 1 left behind instead of generating them again.
-static int shard_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *j, size_t i, std::vector<ChipTrace> *traces, bool reuse) {
+static int shard_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *j, ShardJob &s, std::vector<ChipTrace> *traces, bool reuse) {
     hipStream_t st = p->eng.stream;
-    ShardJob &s = j->shards[i];
     const MachineDesc *m = machine_rv32();
+    if (!s.d_cpu && (!j->d_cpu || j->work_log_cpu < s.log_n[RV32_CHIP_CPU])) {   // working buffers, sized for the largest shard seen
+        HIP_TRY(p, hipStreamSynchronize(st));
+        for (uint32_t **d : {&j->d_cpu, &j->d_byte, &j->d_prog}) { if (*d) (void)hipFree(*d); *d = nullptr; }
+        j->work_log_cpu = s.log_n[RV32_CHIP_CPU];
+        HIP_TRY(p, hipMalloc(&j->d_cpu, ((size_t)RV32_CPU_MAIN_W << j->work_log_cpu) * 4));
+        HIP_TRY(p, hipMalloc(&j->d_byte, j->byte_words * 4));
+        HIP_TRY(p, hipMalloc(&j->d_prog, j->prog_words * 4));
+    }
     uint32_t *cpu = s.d_cpu ? s.d_cpu : j->d_cpu, *byte = s.d_cpu ? s.d_byte : j->d_byte, *prog = s.d_cpu ? s.d_prog : j->d_prog;
     if (!(reuse && s.d_cpu && s.traces_valid)) {
         bool ok = hipMemcpyAsync(byte, s.d_aux[RV32_CHIP_BYTE], j->byte_words * 4, hipMemcpyDeviceToDevice, st) == hipSuccess &&
                   hipMemcpyAsync(prog, s.d_aux[RV32_CHIP_PROGRAM], j->prog_words * 4, hipMemcpyDeviceToDevice, st) == hipSuccess &&
-                  rv32::launch_k0_cpu_rows(st, s.d_recs, s.n_recs, s.index, s.pv_end, pk->d_instrs, pk->d_prog_row, cpu, s.log_n[RV32_CHIP_CPU], byte, prog) == hipSuccess &&
+                  rv32::launch_k0_cpu_rows(st, s.d_recs, s.n_recs, s.index, s.next_pc, pk->d_instrs, pk->d_prog_row, cpu, s.log_n[RV32_CHIP_CPU], byte, prog) == hipSuccess &&
                   launch_to_internal(st, byte, j->byte_words) == hipSuccess && launch_to_internal(st, prog, j->prog_words) == hipSuccess;
         if (!ok) return fail(p, DVT_ERR_DEVICE, "trace generation (K0) failed: %s", hipGetErrorString(hipGetLastError()));
         s.traces_valid = s.d_cpu != nullptr;
@@ -525,9 +508,9 @@ static int shard_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *j, size_t i, s
     return DVT_OK;
 }
 
-static int shard_commit(dvt_prover *p, const dvt_pk *pk, dvt_job *j, size_t i, uint32_t header[HEADER_WORDS]) {
+// phase 1 of a shard: K0 + K1..K3 of the main traces -> header
+static int shard_commit(dvt_prover *p, const dvt_pk *pk, dvt_job *j, ShardJob &s) {
     std::vector<ChipTrace> traces;
-    ShardJob &s = j->shards[i];
     // keep the phase-1 results in HBM while they fit (about 3 GB per 2^21-cycle shard); otherwise phase 2 recomputes
     size_t free_b = 0, total_b = 0;
     if (p->keep_phase1 && !s.cache.tree) (void)hipMemGetInfo(&free_b, &total_b);   // (only the first commit of a shard asks)
@@ -540,24 +523,27 @@ static int shard_commit(dvt_prover *p, const dvt_pk *pk, dvt_job *j, size_t i, u
             for (uint32_t **d : {&s.d_cpu, &s.d_byte, &s.d_prog}) { if (*d) (void)hipFree(*d); *d = nullptr; }
         }
     }
-    int rc = shard_traces(p, pk, j, i, &traces, false);
+    int rc = shard_traces(p, pk, j, s, &traces, false);
     if (rc) return rc;
     Digest root;
     if (!p->eng.commit_main_root(pk->key, traces, &root, keep)) return fail(p, DVT_ERR_DEVICE, "%s", p->eng.err.c_str());
-    for (int k = 0; k < 8; k++) header[k] = root.d[k].canonical();
-    for (uint32_t k = 0; k < N_PUB; k++) header[8 + k] = j->shards[i].pubs[k].canonical();
+    for (int k = 0; k < 8; k++) s.header[k] = root.d[k].canonical();
+    for (uint32_t k = 0; k < N_PUB; k++) s.header[8 + k] = s.pubs[k].canonical();
+    s.header_valid = true;
     return DVT_OK;
 }
 
-static int shard_prove(dvt_prover *p, const dvt_pk *pk, dvt_job *j, size_t i, const PermChallenges &gc, std::vector<uint32_t> *words) {
+// phase 2 of a shard: K0..K9 with the common challenges -> shard proof words
+static int shard_prove(dvt_prover *p, const dvt_pk *pk, dvt_job *j, ShardJob &s, const PermChallenges &gc, std::vector<uint32_t> *words) {
     std::vector<ChipTrace> traces;
-    int rc = shard_traces(p, pk, j, i, &traces, j->shards[i].cache.valid);
+    int rc = shard_traces(p, pk, j, s, &traces, s.cache.valid);
     if (rc) return rc;
     ShardProof sp;
-    bool ok = p->eng.prove_shard(pk->key, traces, j->shards[i].pubs, p->cfg, &sp, &gc, &j->shards[i].cache);
+    bool ok = p->eng.prove_shard(pk->key, traces, s.pubs, p->cfg, &sp, &gc, &s.cache);
     (void)hipStreamSynchronize(p->eng.stream);
-    j->shards[i].cache.valid = false;  // the buffers stay for the next commit of this shard (released with the job)
-    j->shards[i].traces_valid = false;
+    s.cache.valid = false;  // the buffers stay for the next commit of this shard (released with the job)
+    s.traces_valid = false;
+    s.header_valid = false;
     if (!ok) return fail(p, DVT_ERR_DEVICE, "%s", p->eng.err.c_str());
     WordWriter w;
     w.w.reserve((size_t)1 << 20);  // a shard proof is about 2.4 MB at 100 queries
@@ -566,12 +552,254 @@ static int shard_prove(dvt_prover *p, const dvt_pk *pk, dvt_job *j, size_t i, co
     return DVT_OK;
 }
 
+// ------------------------------------------------------------------ the prepare pipeline
+// One sequential FAST pass of the guest finds the shard boundaries and snapshots the machine there; trace-mode
+// executor threads re-run the owned shards from the snapshots into pinned buffers and build the small auxiliary
+// traces; the calling thread uploads shard i+1 on the copy stream while the GPU runs phase 1 (K0 + K1..K3 of the main
+// traces) of shard i.  (reference src/main.rs:461-466: prove() executes AND proves in one call.)
+namespace {
+struct ReadyShard {
+    rv32::CycleRec *buf = nullptr;
+    rv32::ShardMeta meta{};
+    rv32::HostTraces aux;
+    std::string err;
+    bool unsupported = false;
+};
+struct Pipeline {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::pair<size_t, rv32::Snapshot>> snaps;
+    bool snaps_closed = false, abort = false, fast_done = false;
+    std::vector<rv32::CycleRec *> free_bufs;
+    std::map<size_t, ReadyShard> ready;
+    // results of the fast pass
+    size_t n_total = 0;
+    std::vector<rv32::MemInitRow> mem_rows;
+    int exit_code = -1;
+    bool halted = false, unsupported = false;
+    uint64_t cycles = 0;
+    std::string error, unsupported_what;
+    std::vector<uint8_t> public_values;
+    uint32_t committed[8] = {}, committed_mask = 0;
+};
+}  // namespace
+
+static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_bufs, size_t nbuf, size_t first, size_t stride, dvt_job **out,
+                       dvt_report *report) {
+    HIP_TRY(p, hipSetDevice(p->eng.device));
+    if (stride == 0 || first >= stride) return fail(p, DVT_ERR_INPUT, "bad shard partition %zu / %zu", first, stride);
+    const std::vector<std::vector<uint8_t>> inputs = collect_stdin(stdin_bufs, nbuf);
+    const rv32::Program &prog = pk->prog;
+    const uint32_t log_shard = p->log_shard;
+    const uint64_t max_cycles = p->max_cycles;
+    unsigned hw = std::thread::hardware_concurrency();
+    const unsigned n_workers = p->exec_threads ? p->exec_threads : std::max(1u, std::min(6u, hw > 3 ? hw - 2 : 1u));
+    // pinned staging: one buffer per worker + two in flight on the GPU side
+    const size_t want_bufs = n_workers + 2;
+    while (p->pinned.size() < want_bufs) {
+        rv32::CycleRec *b = nullptr;
+        HIP_TRY(p, hipHostMalloc(&b, sizeof(rv32::CycleRec) << log_shard));
+        p->pinned.push_back(b);
+    }
+    Pipeline pl;
+    pl.free_bufs = p->pinned;
+
+    std::thread fast([&] {
+        rv32::Vm vm(prog, &inputs, log_shard);
+        size_t pos = 0;
+        for (;; pos++) {
+            if (pos % stride == first) {
+                rv32::Snapshot snap = vm.snapshot();
+                std::unique_lock<std::mutex> lk(pl.mu);
+                pl.cv.wait(lk, [&] { return pl.snaps.size() < 2 * (size_t)n_workers + 2 || pl.abort; });
+                if (pl.abort) break;
+                pl.snaps.emplace_back(pos, std::move(snap));
+                pl.cv.notify_all();
+            }
+            vm.run_shard(false, nullptr, max_cycles);
+            if (!vm.error.empty() || vm.halted || !vm.next_shard()) break;
+        }
+        std::vector<rv32::MemInitRow> rows;
+        if (vm.halted) rows = vm.mem_rows();
+        std::lock_guard<std::mutex> lk(pl.mu);
+        pl.n_total = pos + 1;
+        pl.mem_rows = std::move(rows);
+        pl.exit_code = vm.exit_code; pl.halted = vm.halted; pl.cycles = vm.cycles; pl.error = vm.error;
+        pl.unsupported = vm.unsupported; pl.unsupported_what = vm.unsupported_what;
+        pl.public_values = std::move(vm.public_values);
+        for (int k = 0; k < 8; k++) pl.committed[k] = vm.committed[k];
+        pl.committed_mask = vm.committed_mask;
+        pl.fast_done = pl.snaps_closed = true;
+        pl.cv.notify_all();
+    });
+    std::vector<std::thread> workers;
+    for (unsigned w = 0; w < n_workers; w++)
+        workers.emplace_back([&] {
+            for (;;) {
+                rv32::CycleRec *buf = nullptr;
+                size_t pos = 0;
+                rv32::Snapshot snap;
+                {
+                    // a buffer first, then the OLDEST snapshot: buffers are handed out in shard order, so the shard the GPU
+                    // thread waits for always has one
+                    std::unique_lock<std::mutex> lk(pl.mu);
+                    pl.cv.wait(lk, [&] { return pl.abort || ((!pl.snaps.empty() || pl.snaps_closed) && (!pl.free_bufs.empty() || pl.snaps.empty())); });
+                    if (pl.abort || pl.snaps.empty()) return;
+                    buf = pl.free_bufs.back();
+                    pl.free_bufs.pop_back();
+                    pos = pl.snaps.front().first;
+                    snap = std::move(pl.snaps.front().second);
+                    pl.snaps.pop_front();
+                    pl.cv.notify_all();
+                }
+                ReadyShard r;
+                r.buf = buf;
+                {
+                    rv32::Vm vm(prog, &inputs, log_shard, snap);
+                    snap = rv32::Snapshot();
+                    rv32::ShardOut so;
+                    so.recs = buf;
+                    vm.run_shard(true, &so, max_cycles);
+                    r.meta = rv32::ShardMeta{so.index, so.start_pc, so.next_pc, so.n_recs};
+                    if (!vm.error.empty()) { r.err = vm.error; r.unsupported = vm.unsupported; }
+                    else {
+                        const std::vector<rv32::MemInitRow> *rows = nullptr;
+                        int ec = 0;
+                        if (vm.halted) {   // the last shard carries the mem_init table: final memory state of the fast pass
+                            std::unique_lock<std::mutex> lk(pl.mu);
+                            pl.cv.wait(lk, [&] { return pl.fast_done || pl.abort; });
+                            rows = &pl.mem_rows;
+                            ec = pl.exit_code;
+                        }
+                        std::string e;
+                        if (!pl.abort && !rv32::build_aux_host(r.meta, so.alu, rows, ec, pk->prep, &r.aux, &e)) r.err = e;
+                    }
+                }
+                std::lock_guard<std::mutex> lk(pl.mu);
+                pl.ready[pos] = std::move(r);
+                pl.cv.notify_all();
+            }
+        });
+
+    dvt_job *j = new dvt_job();
+    j->first = first; j->stride = stride;
+    j->byte_words = (size_t)rv32::N_BYTE_OPS * 65536;
+    j->prog_words = (size_t)1 << pk->prep.log_n[RV32_CHIP_PROGRAM];
+    const MachineDesc *m = machine_rv32();
+    int rc = DVT_OK;
+    hipEvent_t ev = nullptr;
+    (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    auto give_back = [&](rv32::CycleRec *b) {
+        std::lock_guard<std::mutex> lk(pl.mu);
+        pl.free_bufs.push_back(b);
+        pl.cv.notify_all();
+    };
+    // upload of one ready shard: records on the copy stream (pinned source, overlaps the compute stream), the small
+    // auxiliary traces on the compute stream
+    auto upload = [&](ReadyShard &r) -> int {
+        j->shards.emplace_back();
+        ShardJob &s = j->shards.back();
+        s.index = r.meta.index; s.n_recs = r.meta.n_recs; s.next_pc = r.meta.next_pc;
+        for (int c = 0; c < m->n_chips; c++) { s.log_n[c] = r.aux.log_n[c]; s.present[c] = r.aux.present[c]; }
+        HIP_TRY(p, hipMalloc(&s.d_recs, s.n_recs * sizeof(rv32::CycleRec)));
+        HIP_TRY(p, hipMemcpyAsync(s.d_recs, r.buf, s.n_recs * sizeof(rv32::CycleRec), hipMemcpyHostToDevice, p->copy_stream));
+        HIP_TRY(p, hipEventRecord(ev, p->copy_stream));
+        for (int c = 0; c < m->n_chips; c++) {
+            if (c == RV32_CHIP_CPU || !s.present[c]) continue;
+            size_t words = r.aux.main[c].size();
+            HIP_TRY(p, hipMalloc(&s.d_aux[c], words * 4));
+            HIP_TRY(p, hipMemcpyAsync(s.d_aux[c], r.aux.main[c].data(), words * 4, hipMemcpyHostToDevice, p->eng.stream));
+            // byte / program multiplicities stay plain integers until K0 has added the cpu rows' lookups
+            if (c != RV32_CHIP_BYTE && c != RV32_CHIP_PROGRAM) HIP_TRY(p, launch_to_internal(p->eng.stream, s.d_aux[c], words));
+        }
+        HIP_TRY(p, hipStreamSynchronize(p->eng.stream));   // r.aux is pageable and about to be released
+        for (auto x : r.aux.pubs) s.pubs.push_back(Fp::from_canonical(x));
+        return DVT_OK;
+    };
+    {
+        bool have_prev = false;
+        rv32::CycleRec *prev_buf = nullptr;
+        for (size_t pos = first; rc == DVT_OK; pos += stride) {
+            ReadyShard r;
+            bool got = false;
+            {
+                std::unique_lock<std::mutex> lk(pl.mu);
+                const auto t0 = std::chrono::steady_clock::now();
+                pl.cv.wait(lk, [&] { return pl.ready.count(pos) || (pl.fast_done && pos >= pl.n_total) || (pl.fast_done && !pl.error.empty()); });
+                j->t_exec_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                auto it = pl.ready.find(pos);
+                if (it != pl.ready.end()) { r = std::move(it->second); pl.ready.erase(it); got = true; }
+            }
+            if (got && !r.err.empty()) {
+                rc = r.unsupported ? fail(p, DVT_ERR_UNSUPPORTED, "no chip for an instruction of the guest (%s)", r.err.c_str())
+                                   : fail(p, DVT_ERR_GUEST, "guest trapped: %s", r.err.c_str());
+                give_back(r.buf);
+                break;
+            }
+            if (got) rc = upload(r);
+            // phase 1 of the previous shard runs while the copy engine brings this one in
+            if (rc == DVT_OK && have_prev) {
+                ShardJob &ps = j->shards[j->shards.size() - (got ? 2 : 1)];
+                rc = shard_commit(p, pk, j, ps);
+                give_back(prev_buf);
+            }
+            if (!got) { have_prev = false; break; }
+            if (rc == DVT_OK) {
+                HIP_TRY(p, hipStreamWaitEvent(p->eng.stream, ev, 0));
+                // (the event is re-recorded per shard: wait for this copy before the buffer can be reused / the event re-armed)
+                if (hipEventSynchronize(ev) != hipSuccess) rc = fail(p, DVT_ERR_DEVICE, "record upload failed");
+            }
+            have_prev = true;
+            prev_buf = r.buf;
+        }
+        if (rc == DVT_OK && have_prev) {
+            rc = shard_commit(p, pk, j, j->shards.back());
+            give_back(prev_buf);
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lk(pl.mu);
+        pl.abort = true;   // (everything is done on the success path; on errors this stops the threads)
+        pl.cv.notify_all();
+    }
+    fast.join();
+    for (auto &w : workers) w.join();
+    (void)hipEventDestroy(ev);
+    if (report) {
+        report->cycles = pl.cycles;
+        report->exit_code = pl.halted ? pl.exit_code : -1;
+        report->halted = pl.halted;
+        report->unprovable = pl.unsupported;
+    }
+    if (rc == DVT_OK) {
+        if (!pl.error.empty()) rc = fail(p, DVT_ERR_GUEST, "guest trapped: %s", pl.error.c_str());
+        else if (pl.unsupported) rc = fail(p, DVT_ERR_UNSUPPORTED, "no chip for %s", pl.unsupported_what.c_str());
+        else if (pl.exit_code != 0) rc = fail(p, DVT_ERR_GUEST, "guest halted with exit code %d", pl.exit_code);
+        else {
+            uint32_t want[8];
+            pv_digest_words(pl.public_values, want);
+            bool ok = pl.committed_mask == 0xff;
+            for (int k = 0; ok && k < 8; k++) ok = pl.committed[k] == want[k];
+            if (!ok) rc = fail(p, DVT_ERR_GUEST, "guest did not COMMIT the SHA-256 digest of the %zu public-value bytes it wrote to fd 3", pl.public_values.size());
+        }
+    } else if (pl.unsupported && rc == DVT_ERR_GUEST) {
+        rc = fail(p, DVT_ERR_UNSUPPORTED, "no chip for %s", pl.unsupported_what.c_str());
+    }
+    if (rc) { job_release(j); return rc; }
+    j->exit_code = pl.exit_code;
+    j->cycles = pl.cycles;
+    j->public_values = std::move(pl.public_values);
+    j->n_total = pl.n_total;
+    *out = j;
+    return DVT_OK;
+}
+
 static std::vector<uint32_t> assemble_container(const dvt_job *j, const std::vector<std::vector<uint32_t>> &shards) {
     WordWriter w;
     w.u32(CORE_PROOF_MAGIC);
     w.u32((uint32_t)shards.size());
-    w.u32((uint32_t)j->res.exit_code);
-    const auto &pv = j->res.public_values;
+    w.u32((uint32_t)j->exit_code);
+    const auto &pv = j->public_values;
     w.u32((uint32_t)pv.size());
     for (size_t i = 0; i < pv.size(); i += 4) {
         uint32_t v = 0;
@@ -585,19 +813,23 @@ static std::vector<uint32_t> assemble_container(const dvt_job *j, const std::vec
     return w.w;
 }
 
-// both phases on one GPU (no lock)
+// both phases on one GPU (no lock); the job must hold every shard of the execution
 static int job_prove(dvt_prover *p, const dvt_pk *pk, dvt_job *j, uint8_t **proof, size_t *proof_len) {
     HIP_TRY(p, hipSetDevice(p->eng.device));
     const size_t n = j->shards.size();
+    if (n != j->n_total) return fail(p, DVT_ERR_INPUT, "this job holds %zu of the execution's %zu shards: prove them shard by shard", n, j->n_total);
     std::vector<uint32_t> headers(n * HEADER_WORDS);
     for (size_t i = 0; i < n; i++) {
-        int rc = shard_commit(p, pk, j, i, headers.data() + i * HEADER_WORDS);
-        if (rc) return rc;
+        if (!j->shards[i].header_valid) {
+            int rc = shard_commit(p, pk, j, j->shards[i]);
+            if (rc) return rc;
+        }
+        memcpy(headers.data() + i * HEADER_WORDS, j->shards[i].header, sizeof(uint32_t) * HEADER_WORDS);
     }
     PermChallenges gc = global_challenges(pk->key.vk, headers.data(), n);
     std::vector<std::vector<uint32_t>> shards(n);
     for (size_t i = 0; i < n; i++) {
-        int rc = shard_prove(p, pk, j, i, gc, &shards[i]);
+        int rc = shard_prove(p, pk, j, j->shards[i], gc, &shards[i]);
         if (rc) return rc;
     }
     (void)hipStreamSynchronize(p->eng.stream);
@@ -650,10 +882,11 @@ int dvt_setup(dvt_prover *p, const uint8_t *elf, size_t elf_len, dvt_pk **pk_out
     return DVT_OK;
 }
 
-int dvt_execute(const uint8_t *elf, size_t elf_len, const dvt_buf *stdin_bufs, size_t nbuf, uint64_t max_cycles,
-                uint8_t **public_values, size_t *pv_len, dvt_report *report, char **err_text) {
+int dvt_execute_io(const uint8_t *elf, size_t elf_len, const dvt_buf *stdin_bufs, size_t nbuf, uint64_t max_cycles,
+                   uint8_t **public_values, size_t *pv_len, uint8_t **stdout_bytes, size_t *stdout_len, dvt_report *report, char **err_text) {
     if (err_text) *err_text = nullptr;
     if (public_values) *public_values = nullptr;
+    if (stdout_bytes) *stdout_bytes = nullptr;
     if (!elf || (nbuf && !stdin_bufs)) return DVT_ERR_INPUT;
     rv32::Program prog;
     std::string err;
@@ -663,8 +896,14 @@ int dvt_execute(const uint8_t *elf, size_t elf_len, const dvt_buf *stdin_bufs, s
     }
     rv32::ExecResult res;
     rv32::execute(prog, collect_stdin(stdin_bufs, nbuf), false, max_cycles ? max_cycles : ~0ull, 21, &res);
-    fill_report(report, res);
+    if (report) {
+        report->cycles = res.cycles;
+        report->exit_code = res.halted ? res.exit_code : -1;
+        report->halted = res.halted;
+        report->unprovable = res.unsupported;
+    }
     if (public_values) *public_values = dup_bytes(res.public_values, pv_len);
+    if (stdout_bytes) *stdout_bytes = dup_bytes(res.stdout_bytes, stdout_len);
     if (!res.error.empty()) {
         if (err_text) *err_text = strdup(res.error.c_str());
         return DVT_ERR_GUEST;
@@ -675,12 +914,20 @@ int dvt_execute(const uint8_t *elf, size_t elf_len, const dvt_buf *stdin_bufs, s
     }
     return DVT_OK;
 }
+int dvt_execute(const uint8_t *elf, size_t elf_len, const dvt_buf *stdin_bufs, size_t nbuf, uint64_t max_cycles,
+                uint8_t **public_values, size_t *pv_len, dvt_report *report, char **err_text) {
+    return dvt_execute_io(elf, elf_len, stdin_bufs, nbuf, max_cycles, public_values, pv_len, nullptr, nullptr, report, err_text);
+}
 
 int dvt_rv32_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_bufs, size_t nbuf, dvt_job **job, dvt_report *report) {
+    return dvt_rv32_prepare_part(p, pk, stdin_bufs, nbuf, 0, 1, job, report);
+}
+int dvt_rv32_prepare_part(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_bufs, size_t nbuf, size_t first, size_t stride, dvt_job **job,
+                          dvt_report *report) {
     if (!p || !pk || !job || (nbuf && !stdin_bufs)) return fail(p, DVT_ERR_INPUT, "null argument");
     if (!pk->is_rv32) return fail(p, DVT_ERR_INPUT, "proving key was not made by dvt_setup");
     std::lock_guard<std::mutex> lk(p->mu);
-    return job_prepare(p, pk, stdin_bufs, nbuf, job, report);
+    return job_prepare(p, pk, stdin_bufs, nbuf, first, stride, job, report);
 }
 int dvt_rv32_prove_job(dvt_prover *p, const dvt_pk *pk, dvt_job *job, uint8_t **proof, size_t *proof_len) {
     if (!p || !pk || !job || (proof && !proof_len)) return fail(p, DVT_ERR_INPUT, "null argument");
@@ -693,14 +940,23 @@ void dvt_job_free(dvt_prover *p, dvt_job *job) {
     (void)hipSetDevice(p->eng.device);
     job_release(job);
 }
-size_t dvt_rv32_job_shards(const dvt_job *job) { return job ? job->shards.size() : 0; }
+size_t dvt_rv32_job_shards(const dvt_job *job) { return job ? job->n_total : 0; }
+double dvt_rv32_job_exec_wait_seconds(const dvt_job *job) { return job ? job->t_exec_wait : 0.0; }
 
-int dvt_rv32_commit_shard(dvt_prover *p, const dvt_pk *pk, dvt_job *job, size_t shard, uint32_t header[15]) {
-    if (!p || !pk || !job || !header || shard >= job->shards.size()) return fail(p, DVT_ERR_INPUT, "bad argument");
+int dvt_rv32_commit_shard(dvt_prover *p, const dvt_pk *pk, dvt_job *job, size_t shard, uint32_t *header) {
+    if (!p || !pk || !job || !header) return fail(p, DVT_ERR_INPUT, "bad argument");
+    ShardJob *s = job->at(shard);
+    if (!s) return fail(p, DVT_ERR_INPUT, "shard %zu is not held by this job", shard);
     std::lock_guard<std::mutex> lk(p->mu);
     HIP_TRY(p, hipSetDevice(p->eng.device));
-    return shard_commit(p, pk, job, shard, header);
+    if (!s->header_valid) {   // (the prepare pipeline already ran phase 1; a second proof of the same job runs it again)
+        int rc = shard_commit(p, pk, job, *s);
+        if (rc) return rc;
+    }
+    memcpy(header, s->header, sizeof(uint32_t) * HEADER_WORDS);
+    return DVT_OK;
 }
+uint32_t dvt_rv32_header_words(void) { return HEADER_WORDS; }
 int dvt_rv32_challenges(const uint8_t *vk, size_t vk_len, const uint32_t *headers, size_t n, uint32_t out[8]) {
     VerifyingKey key;
     if (!vk || !headers || !out || !n || !vk_parse(vk, vk_len, &key)) return DVT_ERR_INPUT;
@@ -712,7 +968,9 @@ int dvt_rv32_challenges(const uint8_t *vk, size_t vk_len, const uint32_t *header
 }
 int dvt_rv32_prove_shard(dvt_prover *p, const dvt_pk *pk, dvt_job *job, size_t shard, const uint32_t challenges[8], uint8_t **proof,
                          size_t *proof_len) {
-    if (!p || !pk || !job || !challenges || shard >= job->shards.size() || (proof && !proof_len)) return fail(p, DVT_ERR_INPUT, "bad argument");
+    if (!p || !pk || !job || !challenges || (proof && !proof_len)) return fail(p, DVT_ERR_INPUT, "bad argument");
+    ShardJob *s = job->at(shard);
+    if (!s) return fail(p, DVT_ERR_INPUT, "shard %zu is not held by this job", shard);
     std::lock_guard<std::mutex> lk(p->mu);
     HIP_TRY(p, hipSetDevice(p->eng.device));
     PermChallenges gc;
@@ -722,13 +980,13 @@ int dvt_rv32_prove_shard(dvt_prover *p, const dvt_pk *pk, dvt_job *job, size_t s
         gc.beta.c[k] = Fp::from_canonical(challenges[4 + k]);
     }
     std::vector<uint32_t> words;
-    int rc = shard_prove(p, pk, job, shard, gc, &words);
+    int rc = shard_prove(p, pk, job, *s, gc, &words);
     if (rc || !proof) return rc;
     *proof = copy_out(words, proof_len);
     return *proof ? DVT_OK : fail(p, DVT_ERR_DEVICE, "out of host memory");
 }
 int dvt_rv32_assemble(const dvt_job *job, const uint8_t *const *shard_proofs, const size_t *lens, size_t n, uint8_t **proof, size_t *proof_len) {
-    if (!job || !shard_proofs || !lens || !proof || !proof_len || n != job->shards.size()) return DVT_ERR_INPUT;
+    if (!job || !shard_proofs || !lens || !proof || !proof_len || n != job->n_total) return DVT_ERR_INPUT;
     std::vector<std::vector<uint32_t>> shards(n);
     for (size_t i = 0; i < n; i++) {
         if (lens[i] % 4 || !shard_proofs[i]) return DVT_ERR_INPUT;
@@ -745,7 +1003,7 @@ int dvt_prove_core(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_bufs, s
     if (!pk->is_rv32) return fail(p, DVT_ERR_INPUT, "proving key was not made by dvt_setup");
     std::lock_guard<std::mutex> lk(p->mu);
     dvt_job *j = nullptr;
-    int rc = job_prepare(p, pk, stdin_bufs, nbuf, &j, report);
+    int rc = job_prepare(p, pk, stdin_bufs, nbuf, 0, 1, &j, report);
     if (rc) return rc;
     rc = job_prove(p, pk, j, proof, proof_len);
     job_release(j);
@@ -766,6 +1024,9 @@ int dvt_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, size_t pr
     if (proof_len % 4) return reject(DVT_ERR_REJECTED, "proof length is not a multiple of 4");
     std::vector<uint32_t> words(proof_len / 4);
     memcpy(words.data(), proof, proof_len);
+    // the caller states the FRI parameters it accepts; refuse settings that verify nothing
+    // (blow-up 2: one bit of security per query, plus the proof-of-work bits)
+    if (fri_queries == 0 || fri_queries > 1024 || pow_bits > 30) return reject(DVT_ERR_INPUT, "fri_queries must be 1..1024 and pow_bits <= 30");
     StarkConfig cfg;
     cfg.num_queries = fri_queries;
     cfg.pow_bits = pow_bits;
@@ -805,12 +1066,12 @@ int dvt_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, size_t pr
             if (last && pubv[1] != 0) return reject(DVT_ERR_REJECTED, "execution did not halt");
             if (!last && pubv[1] == 0) return reject(DVT_ERR_REJECTED, "halt before the last shard");
             if (last && pubv[2] != ec % P) return reject(DVT_ERR_REJECTED, "exit code mismatch");
-            if (pubv[5] != (i ? sps[i - 1].public_values[6].canonical() : 0u)) return reject(DVT_ERR_REJECTED, "public-value counters do not chain");
-            if (pubv[6] < pubv[5]) return reject(DVT_ERR_REJECTED, "public-value counter decreases");
-            if (last && (pvl % 4 || pubv[6] != pvl / 4)) return reject(DVT_ERR_REJECTED, "number of committed public-value words does not match");
             // chip set: program, byte, cpu, mem_image always; mem_init in the last shard only; shift / muldiv when the shard uses them
             bool have[rv32::N_CHIPS] = {};
-            for (auto &c : sp.chips) have[c.chip_id] = true;
+            for (auto &c : sp.chips) {
+                if (c.chip_id >= (uint32_t)rv32::N_CHIPS) return reject(DVT_ERR_REJECTED, "chip id out of range");
+                have[c.chip_id] = true;
+            }
             for (int c : {RV32_CHIP_PROGRAM, RV32_CHIP_BYTE, RV32_CHIP_CPU, RV32_CHIP_MEM_IMAGE})
                 if (!have[c]) return reject(DVT_ERR_REJECTED, "a mandatory chip is missing from a shard");
             if (have[RV32_CHIP_MEM_INIT] != last) return reject(DVT_ERR_REJECTED, "mem_init must be part of exactly the last shard");
@@ -825,19 +1086,22 @@ int dvt_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, size_t pr
             if (!why.empty()) return reject(DVT_ERR_REJECTED, "shard " + std::to_string(i + 1) + ": " + why);
             total += t;
         }
-        // the receiving side of the public-values bus is supplied here, from the claimed bytes:
-        // word k contributes 1 / (alpha + bus + beta*k + beta^2 b0 + ... + beta^5 b3)
+        // The receiving side of the public-values bus is supplied here, from the claimed bytes: an SP1 guest commits the
+        // eight words of SHA-256(public-value bytes) with COMMIT(k, word k); tuple k contributes
+        // 1 / (alpha + bus + beta k + beta^2 b0 + ... + beta^5 b3), b = the bytes of digest word k.
         {
+            uint8_t dg[32];
+            sha256(pv.data(), pv.size(), dg);
             Fp4 bp[5];
             bp[0] = gc.beta;
             for (int k = 1; k < 5; k++) bp[k] = bp[k - 1] * gc.beta;
             Fp4 expect = Fp4::zero();
-            for (uint32_t k = 0; k < pvl / 4; k++) {
-                Fp4 d = gc.alpha + Fp::from_canonical(5) + bp[0] * Fp::from_canonical(k);
-                for (int b = 0; b < 4; b++) d += bp[1 + b] * Fp::from_canonical(pv[4 * k + b]);
+            for (uint32_t k = 0; k < 8; k++) {
+                Fp4 d = gc.alpha + Fp::from_canonical(PV_BUS) + bp[0] * Fp::from_canonical(k);
+                for (int b = 0; b < 4; b++) d += bp[1 + b] * Fp::from_canonical(dg[4 * k + b]);
                 expect += inv(d);
             }
-            if (total != expect) return reject(DVT_ERR_REJECTED, "LogUp cumulative sums do not cancel across the shards (memory bus or public values)");
+            if (total != expect) return reject(DVT_ERR_REJECTED, "LogUp cumulative sums do not cancel across the shards (memory bus or public-values digest)");
         }
         if (exit_code) *exit_code = (int32_t)ec;
         if (public_values) *public_values = dup_bytes(pv, pv_len);
@@ -890,11 +1154,12 @@ int dvt_rv32_debug_traces(const uint8_t *elf, size_t elf_len, const dvt_buf *std
 // test hook: run K0 on shard `shard` of a prepared job and return the device-generated main traces (canonical),
 // same blob layout as dvt_rv32_debug_traces but without preprocessed columns (prep_width = 0)
 int dvt_rv32_debug_device_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *j, size_t shard, uint32_t **blob, size_t *blob_words) {
-    if (!p || !pk || !j || !blob || !blob_words || shard >= j->shards.size()) return fail(p, DVT_ERR_INPUT, "bad argument");
+    if (!p || !pk || !j || !blob || !blob_words || !j->at(shard)) return fail(p, DVT_ERR_INPUT, "bad argument");
     std::lock_guard<std::mutex> lk(p->mu);
     HIP_TRY(p, hipSetDevice(p->eng.device));
     std::vector<ChipTrace> traces;
-    int rc = shard_traces(p, pk, j, shard, &traces, false);
+    ShardJob &sj = *j->at(shard);
+    int rc = shard_traces(p, pk, j, sj, &traces, false);
     if (rc) return rc;
     HIP_TRY(p, hipStreamSynchronize(p->eng.stream));
     const MachineDesc *m = machine_rv32();
@@ -908,7 +1173,7 @@ int dvt_rv32_debug_device_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *j, si
         HIP_TRY(p, hipMemcpy(T.main[t.chip_id].data(), t.d_main, words * 4, hipMemcpyDeviceToHost));
         for (auto &x : T.main[t.chip_id]) x = Fp::raw(x).canonical();
     }
-    for (auto x : j->shards[shard].pubs) T.pubs.push_back(x.canonical());
+    for (auto x : sj.pubs) T.pubs.push_back(x.canonical());
     std::vector<uint32_t> w = trace_blob(T, nullptr);
     *blob = (uint32_t *)malloc(w.size() * 4);
     if (!*blob) return fail(p, DVT_ERR_DEVICE, "out of host memory");

@@ -106,6 +106,8 @@ inline ShardProof read_shard_proof(WordReader &r) {
     p.chips.resize(nc);
     for (auto &c : p.chips) {
         c.chip_id = r.u32(); c.log_n = r.u32(); c.cumsum = r.ef();
+        // (untrusted input: bound both before anything indexes with them; the machine's own chip count is checked by the verifier)
+        if (c.chip_id >= 64 || c.log_n > 22) throw std::runtime_error("proof: chip id or height out of range");
         c.prep_l = r.efs(1 << 12); c.prep_n = r.efs(1 << 12); c.main_l = r.efs(1 << 12); c.main_n = r.efs(1 << 12);
         c.perm_l = r.efs(1 << 12); c.perm_n = r.efs(1 << 12); c.quot = r.efs(8);
     }

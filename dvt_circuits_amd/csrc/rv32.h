@@ -6,18 +6,22 @@
 //   - ELF32 little-endian RISC-V executable; PT_LOAD segments form the initial
 //     memory image, executable segments are decoded into the program table;
 //     registers start at 0; pc starts at e_entry; all addresses < 2^30.
-//   - ecall: t0 = syscall id, a0..a2 = arguments; ids follow the SP1 v3 guest ABI
-//     observed in the reference's bundled guest:
-//     0x00 HALT(a0 = exit code), 0x02 WRITE(fd,ptr,len), 0x10 COMMIT(a0 = word: appends a
-//     32-bit word to the public values, which the proof binds), 0x1A COMMIT_DEFERRED_PROOFS
-//     (no-op), 0xF0 HINT_LEN (-> t0), 0xF1 HINT_READ(ptr,len).  WRITE is not part of the statement.
+//   - ecall: t0 = syscall id, a0..a2 = arguments; SP1's guest ABI as observed in the reference's
+//     bundled guest: 0x00 HALT(a0 = exit code), 0x02 WRITE(fd,ptr,len) —
+//     fd 3 appends to the public-value byte stream (sp1_zkvm::io::commit, reference
+//     crates/finalization_prove/src/main.rs:26-32), other fds are guest output; 0x10 COMMIT(a0 =
+//     index, a1 = digest word): the guest commits the eight words of SHA-256(public-value bytes)
+//     before HALT, the proof binds them and the verifier recomputes them from the claimed bytes;
+//     0x1A COMMIT_DEFERRED_PROOFS (no-op: core proofs have no recursion), 0xF0 HINT_LEN (-> t0),
+//     0xF1 HINT_READ(ptr,len): the next stdin buffer becomes the initial value of untouched memory.
 //     stdin is a list of byte buffers (SP1Stdin::write, src/main.rs:434-437).
-//   - instructions without a chip yet (mulh/mulhsu, div/rem) execute, but a
-//     program that retires one cannot be proven:
-//     prove returns DVT_ERR_UNSUPPORTED.
+//   - FENCE / EBREAK / CSR instructions execute but have no chip: a program that retires one
+//     cannot be proven (prove returns DVT_ERR_UNSUPPORTED).  Precompile syscalls are not implemented.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "bb.cuh"
@@ -34,12 +38,14 @@ enum Flag : uint32_t {
 };
 constexpr uint32_t B_AND = 1, B_OR = 2, B_XOR = 3, B_LTU = 4, B_MSB = 5, B_RANGE = 6, B_U16 = 7;
 constexpr int N_BYTE_OPS = 7;  // multiplicity columns of the byte chip, in this order: and or xor ltu msb range u16
-constexpr uint32_t ADDR_LIMIT = 1u << 30;
+constexpr uint32_t ADDR_LIMIT = 0x38000000u;  // tools/airgen/rv32.py ADDR_TOP_BYTE: address + address gap stays below p
 constexpr uint32_t SYS_COMMIT = 0x10;
+constexpr uint32_t REG_A1 = 11;
+constexpr uint32_t MAX_SHARDS = 65535;        // shard numbers travel as 16-bit halves of the cycle records
 constexpr uint32_t ALU_SLL = 1, ALU_SRL = 2, ALU_SRA = 3;  // alu-bus opcodes (chips outside the cpu chip): shift chip
 constexpr uint32_t ALU_MULH = 4, ALU_MULHSU = 5, ALU_DIV = 6, ALU_DIVU = 7, ALU_REM = 8, ALU_REMU = 9;  // muldiv chip
 constexpr int N_CHIPS = 7;  // program, byte, cpu, mem_image, mem_init, shift, muldiv
-constexpr uint32_t N_PUBLIC = 7;  // start_pc, next_pc, exit_code, shard, is_last, pv_start, pv_end
+constexpr uint32_t N_PUBLIC = 5;  // start_pc, next_pc, exit_code, shard, is_last
 
 struct Instr {
     uint32_t pc, rd, rs1, rs2, imm, off, tgt, flags;
@@ -54,17 +60,19 @@ struct Program {
     std::vector<std::pair<uint32_t, uint32_t>> image;     // (byte address, word), sorted, word aligned
 };
 
-// One retired instruction, compact (what the host uploads for K0): 16 words.
-// Timestamps are (shard, clk) pairs: *_sh = shard of the previous access, *_ts = its clk.
+// One retired instruction, compact (what the host uploads for K0): 12 words = three 16-byte loads.
+// Timestamps are (shard, clk) pairs: *_ts = clk of the previous access of that port, its shard is a
+// 16-bit half of sh_ab / sh_cm.  Everything else of the row (next pc, memory word after a store, limbs,
+// carries ...) is recomputed by fill_cpu_row on the device.
 struct CycleRec {
     uint32_t idx;      // instruction index in Program::instrs
     uint32_t a, b, c;  // rd value written / rs1 value / rs2-or-immediate value
     uint32_t pa_prev, pa_ts, pb_ts, pc_ts;
-    uint32_t next_pc;
-    uint32_t m_val, m_prev, m_ts;
-    uint32_t pa_sh, pb_sh, pc_sh, m_sh;
-    uint32_t pv_idx;   // public-value words committed (COMMIT ecalls) before this instruction
+    uint32_t m_prev, m_ts;   // memory port (loads, stores, the a1 read of COMMIT): word before the access, previous clk
+    uint32_t sh_ab;    // pa_sh | pb_sh << 16
+    uint32_t sh_cm;    // pc_sh | m_sh << 16
 };
+static_assert(sizeof(CycleRec) == 48, "CycleRec is uploaded as is");
 
 struct MemInitRow {
     uint32_t addr, v, f, fts, fsh, is_img;
@@ -78,7 +86,6 @@ struct AluEvent {
 struct ShardRec {
     std::vector<AluEvent> alu;   // instructions of this shard proven by chips outside the cpu chip
     uint32_t index = 0, start_pc = 0, next_pc = 0;
-    uint32_t pv_start = 0, pv_end = 0;   // committed public-value words before / after this shard
     std::vector<CycleRec> recs;
 };
 
@@ -88,29 +95,109 @@ struct ExecResult {
     uint64_t cycles = 0;
     bool unsupported = false;   // retired an instruction the prover has no chip for
     std::string unsupported_what;
-    std::vector<uint8_t> public_values, stdout_bytes;
+    std::vector<uint8_t> public_values;  // bytes the guest wrote to fd 3
+    std::vector<uint8_t> stdout_bytes;   // bytes written to any other fd
+    uint32_t committed[8] = {};          // digest words passed to COMMIT (index -> word)
+    uint32_t committed_mask = 0;
     std::vector<ShardRec> shards;        // filled only when tracing
     std::vector<MemInitRow> mem_rows;    // sorted by address, filled only when tracing (part of the LAST shard)
     std::string error;                   // non-empty: the guest trapped (bad access, bad pc, ...)
 };
 
 bool load_elf(const uint8_t *elf, size_t n, Program *out, std::string *err);
-// stdin: list of buffers.  trace = keep per-cycle records, cut into shards of 2^log_shard cycles.
-// max_cycles bounds the run.
+
+// ---- the guest machine --------------------------------------------------------
+// A resumable RV32IM interpreter.  Every register / memory word carries the (shard, clk) of its last access,
+// which is what the memory argument of the AIR consumes.  Two modes share one loop:
+//   fast   no per-cycle records: finds the shard boundaries and the architectural state there (snapshots)
+//   trace  one CycleRec per retired instruction + the events of the shift / muldiv chips
+// so that a long execution is cut into shards by ONE sequential fast pass while the shards are re-executed
+// from the snapshots in trace mode on other threads (capi.hip), overlapped with the GPU.
+// Guest memory is paged copy-on-write: a snapshot shares every page the next shard does not touch.
+constexpr uint32_t PAGE_WORD_BITS = 12;
+struct Cell { uint32_t val, ts, sh, flags; };   // flags: 1 = accessed by a load / store, 2 = part of the program image
+struct Page { Cell c[1u << PAGE_WORD_BITS]; };
+constexpr uint32_t N_PAGES = 1u << (30 - 2 - PAGE_WORD_BITS);
+
+struct Snapshot {
+    Cell regs[32];
+    uint32_t pc = 0, shard = 1;
+    uint64_t cycles = 0;
+    size_t next_input = 0;
+    std::vector<std::pair<uint32_t, std::shared_ptr<Page>>> pages;
+};
+
+// where trace mode writes: recs must hold 2^log_shard entries (pinned host memory in the prover)
+struct ShardOut {
+    CycleRec *recs = nullptr;
+    size_t n_recs = 0;
+    std::vector<AluEvent> alu;
+    uint32_t index = 0, start_pc = 0, next_pc = 0;
+};
+
+class Vm {
+  public:
+    Vm(const Program &prog, const std::vector<std::vector<uint8_t>> *stdin_bufs, uint32_t log_shard);
+    Vm(const Program &prog, const std::vector<std::vector<uint8_t>> *stdin_bufs, uint32_t log_shard, const Snapshot &at);
+    Vm(const Vm &) = delete;
+    Snapshot snapshot();   // state at the start of the current shard (call between shards)
+    // Runs the current shard to its end: 2^log_shard cycles, HALT, a trap (error non-empty) or the cycle budget.
+    // Trace mode fills *out.  Afterwards: halted / !error.empty() -> done; otherwise next_shard() and call again.
+    void run_shard(bool trace, ShardOut *out, uint64_t max_total_cycles);
+    bool next_shard();     // false (and error set) when the execution would exceed MAX_SHARDS
+    // mem_init rows of the whole execution (image words + every other word a load / store touched), sorted by address
+    std::vector<MemInitRow> mem_rows() const;
+
+    const Program &prog;
+    uint32_t pc, shard = 1, in_shard = 0, log_shard;
+    uint64_t cycles = 0;
+    bool halted = false, unsupported = false, collect_output = true;
+    int exit_code = -1;
+    std::string error, unsupported_what;
+    std::vector<uint8_t> public_values, stdout_bytes;
+    uint32_t committed[8] = {}, committed_mask = 0;
+
+  private:
+    Cell regs[32];
+    const std::vector<std::vector<uint8_t>> *stdin_bufs;
+    size_t next_input = 0;
+    std::vector<std::shared_ptr<Page>> holders;   // [N_PAGES]
+    std::vector<Page *> raw;
+    std::vector<uint8_t> own;                      // page may be written in place (not shared with a snapshot)
+    std::vector<uint32_t> alloc_pages, owned_pages;
+    std::vector<std::pair<uint32_t, uint32_t>> first_touch;   // (address, value at the first access) of non-image words
+    void make_own(uint32_t pg);
+    Cell &at(uint32_t addr) {   // addr: byte address below ADDR_LIMIT
+        const uint32_t pg = addr >> (PAGE_WORD_BITS + 2);
+        if (!own[pg]) make_own(pg);
+        return raw[pg]->c[(addr >> 2) & ((1u << PAGE_WORD_BITS) - 1)];
+    }
+    const Cell *peek(uint32_t addr) const {
+        const Page *p = raw[addr >> (PAGE_WORD_BITS + 2)];
+        return p ? &p->c[(addr >> 2) & ((1u << PAGE_WORD_BITS) - 1)] : nullptr;
+    }
+    template <bool TRACE> void run(ShardOut *out, uint64_t budget);
+    void trap(const std::string &m);
+};
+
+// Single-threaded convenience over Vm (dvt_execute, the debug trace hooks, tests): stdin = list of buffers;
+// trace = keep per-cycle records, cut into shards of 2^log_shard cycles.  max_cycles bounds the run.
 void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin_bufs, bool trace, uint64_t max_cycles,
              uint32_t log_shard, ExecResult *res);
 
 // ---- trace generation (K0) ---------------------------------------------------
 // Sink interface used by fill_cpu_row:  put(col, canonical value);  byte(op_index, table_row);  prog(idx)
+// next_pc: pc of the next retired instruction (the shard's next_pc public value after its last row).
 template <class Sink>
-DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint32_t shard, Sink &s) {
+DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint32_t shard, uint32_t next_pc, Sink &s) {
     const uint32_t fl = in.flags;
     auto F = [&](uint32_t bit) -> uint32_t { return (fl >> bit) & 1u; };
     auto B = [](uint32_t w, int i) -> uint32_t { return (w >> (8 * i)) & 0xffu; };
     const uint32_t clk = 4 * (row + 1);
+    const uint32_t pa_sh = r.sh_ab & 0xffffu, pb_sh = r.sh_ab >> 16, pc_sh = r.sh_cm & 0xffffu, m_sh = r.sh_cm >> 16;
     s.put(RV32_CPU_clk, clk);
     s.put(RV32_CPU_pc, in.pc);
-    s.put(RV32_CPU_next_pc, r.next_pc);
+    s.put(RV32_CPU_next_pc, next_pc);
     s.put(RV32_CPU_rd, in.rd);
     s.put(RV32_CPU_rs1, in.rs1);
     s.put(RV32_CPU_rs2, in.rs2);
@@ -123,7 +210,6 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
         s.put(RV32_CPU_pa_prev_0 + i, B(r.pa_prev, i));
     }
     s.put(RV32_CPU_aux, in.tgt + in.alu_op);   // target of the control-flow families / alu-bus opcode of F_ALU rows: never both
-    s.put(RV32_CPU_pv_idx, r.pv_idx);
     // flag columns: rd_en, imm_c, then the family flags in FLAGS order (rs1_en, rs2_en and is_real are linear in those)
     s.put(RV32_CPU_rd_en, F(F_RD_EN));
     s.put(RV32_CPU_imm_c, F(F_IMM_C));
@@ -134,26 +220,36 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
     // (shard', clk') < (shard, clk): same shard -> clk difference, earlier shard -> shard difference
     auto gap = [&](uint32_t prev_sh, uint32_t prev_ts, uint32_t ts) -> uint32_t { return prev_sh == shard ? ts - prev_ts - 1 : shard - prev_sh - 1; };
     if (F(F_RS2_EN)) {
-        uint32_t d = gap(r.pc_sh, r.pc_ts, clk);
-        s.put(RV32_CPU_pc_ts, r.pc_ts); s.put(RV32_CPU_pc_sh, r.pc_sh); s.put(RV32_CPU_pc_same, r.pc_sh == shard);
+        uint32_t d = gap(pc_sh, r.pc_ts, clk);
+        s.put(RV32_CPU_pc_ts, r.pc_ts); s.put(RV32_CPU_pc_sh, pc_sh); s.put(RV32_CPU_pc_same, pc_sh == shard);
         s.put(RV32_CPU_pc_lo, d & 0xffff); pc_hi = d >> 16;
         s.byte(B_U16 - 1, d & 0xffff);
     }
     if (F(F_RS1_EN)) {
-        uint32_t d = gap(r.pb_sh, r.pb_ts, clk + 1);
-        s.put(RV32_CPU_pb_ts, r.pb_ts); s.put(RV32_CPU_pb_sh, r.pb_sh); s.put(RV32_CPU_pb_same, r.pb_sh == shard);
+        uint32_t d = gap(pb_sh, r.pb_ts, clk + 1);
+        s.put(RV32_CPU_pb_ts, r.pb_ts); s.put(RV32_CPU_pb_sh, pb_sh); s.put(RV32_CPU_pb_same, pb_sh == shard);
         s.put(RV32_CPU_pb_lo, d & 0xffff); pb_hi = d >> 16;
         s.byte(B_U16 - 1, d & 0xffff);
     }
     if (F(F_RD_EN)) {
-        uint32_t d = gap(r.pa_sh, r.pa_ts, clk + 3);
-        s.put(RV32_CPU_pa_ts, r.pa_ts); s.put(RV32_CPU_pa_sh, r.pa_sh); s.put(RV32_CPU_pa_same, r.pa_sh == shard);
+        uint32_t d = gap(pa_sh, r.pa_ts, clk + 3);
+        s.put(RV32_CPU_pa_ts, r.pa_ts); s.put(RV32_CPU_pa_sh, pa_sh); s.put(RV32_CPU_pa_same, pa_sh == shard);
         s.put(RV32_CPU_pa_lo, d & 0xffff); pa_hi = d >> 16;
         s.byte(B_U16 - 1, d & 0xffff);
     }
     s.put(RV32_CPU_pb_hi, pb_hi); s.put(RV32_CPU_pc_hi, pc_hi); s.put(RV32_CPU_pa_hi, pa_hi);
     const int U = RV32_CPU_u_0;
     const uint32_t a = r.a, b = r.b, c = r.c;
+    // the memory port (loads / stores, the a1 read of COMMIT): u[9..12] word after, u[13..16] word before, u[17] previous
+    // clk, u[8] / u[18] limbs of the timestamp gap, u[19] previous shard, u[20] same-shard flag
+    auto mem_port = [&](uint32_t m_val) {
+        for (int i = 0; i < 4; i++) { s.put(U + 9 + i, B(m_val, i)); s.put(U + 13 + i, B(r.m_prev, i)); }
+        const uint32_t d = gap(m_sh, r.m_ts, clk + 2);
+        m_hi = d >> 16;
+        s.put(U + 17, r.m_ts); s.put(U + 8, d & 0xffff);
+        s.put(U + 18, m_hi); s.put(U + 19, m_sh); s.put(U + 20, m_sh == shard);
+        s.byte(B_U16 - 1, d & 0xffff);
+    };
     if (F(F_ADD) | F(F_SUB)) {
         // carries of (b + c) for ADD, of (a + c) for SUB
         uint32_t x = F(F_ADD) ? b : a, cin = 0;
@@ -223,17 +319,18 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
         }
         s.byte(B_RANGE - 1, (B(sum, 0) << 8) | B(sum, 1));
         s.byte(B_RANGE - 1, (B(sum, 2) << 8) | B(sum, 3));
-        s.byte(B_LTU - 1, (B(sum, 3) << 8) | 0x40);
+        s.byte(B_LTU - 1, (B(sum, 3) << 8) | (ADDR_LIMIT >> 24));
         if (F(F_JALR)) {
             s.put(U + 8, sum & 1);
         } else {
-            for (int i = 0; i < 4; i++) { s.put(U + 9 + i, B(r.m_val, i)); s.put(U + 13 + i, B(r.m_prev, i)); }
-            uint32_t d = gap(r.m_sh, r.m_ts, clk + 2);
-            s.put(U + 17, r.m_ts); s.put(U + 8, d & 0xffff); m_hi = d >> 16;
-            s.put(U + 18, m_hi); s.put(U + 19, r.m_sh); s.put(U + 20, r.m_sh == shard);
-            s.byte(B_U16 - 1, d & 0xffff);
+            // the access moves the whole aligned word; stores patch it
+            const uint32_t o = sum & 3, sh8 = 8 * o;
+            uint32_t m_val = r.m_prev;
+            if (F(F_SW)) m_val = c;
+            else if (F(F_SB)) m_val = (r.m_prev & ~(0xffu << sh8)) | ((c & 0xffu) << sh8);
+            else if (F(F_SH)) m_val = (r.m_prev & ~(0xffffu << sh8)) | ((c & 0xffffu) << sh8);
+            mem_port(m_val);
             s.byte(B_AND - 1, (B(sum, 0) << 8) | 3);
-            const uint32_t o = sum & 3;
             if (o) s.put(U + 20 + o, 1);  // u[21..23]: one-hot of offsets 1..3
             if (F(F_LB) | F(F_LH)) {
                 const uint32_t sbyte = F(F_LB) ? B(a, 0) : B(a, 1);
@@ -243,13 +340,18 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
             }
         }
     } else if (F(F_ECALL)) {
+        // u[4] is_halt, u[5] 1/id, u[6] is_commit, u[7] 1/(id - COMMIT); COMMIT rows read a1 (x11) through the memory port
         uint32_t idc = b % P;
-        s.put(U + 0, idc == 0);
-        if (idc) s.put(U + 1, inv(Fp::from_canonical(idc)).canonical());
+        s.put(U + 4, idc == 0);
+        if (idc) s.put(U + 5, inv(Fp::from_canonical(idc)).canonical());
         const bool is_commit = idc == SYS_COMMIT;
-        s.put(U + 2, is_commit);
-        if (!is_commit) s.put(U + 3, inv(Fp::from_canonical(idc) - Fp::from_canonical(SYS_COMMIT)).canonical());
+        s.put(U + 6, is_commit);
+        if (!is_commit) s.put(U + 7, inv(Fp::from_canonical(idc) - Fp::from_canonical(SYS_COMMIT)).canonical());
         s.put(RV32_CPU_commit_m, is_commit);
+        if (is_commit) {
+            s.put(U + 0, REG_A1);
+            mem_port(r.m_prev);
+        }
     }
     s.byte(B_RANGE - 1, (pb_hi << 8) | pc_hi);
     s.byte(B_RANGE - 1, (pa_hi << 8) | m_hi);
@@ -265,7 +367,7 @@ struct HostTraces {
     uint32_t log_n[N_CHIPS];
     bool present[N_CHIPS];
     std::vector<uint32_t> main[N_CHIPS];
-    std::vector<uint32_t> pubs;   // start_pc, next_pc, exit_code, shard, is_last, pv_start, pv_end
+    std::vector<uint32_t> pubs;   // start_pc, next_pc, exit_code, shard, is_last
 };
 // preprocessed traces (program, byte, mem_image) for setup
 struct HostPrep {
@@ -273,16 +375,22 @@ struct HostPrep {
     std::vector<uint32_t> prep[N_CHIPS];
 };
 void build_prep(const Program &prog, HostPrep *out);
+// Everything of a shard except the cpu trace and the lookups the cpu rows make: shift / muldiv rows, in the last
+// shard (mem_rows != nullptr) the mem_init rows, the byte-table multiplicities those cause, zeroed program / mem_image
+// columns, public values.  The device path (K0) adds the cpu chip and its lookup counts on top.
+struct ShardMeta {
+    uint32_t index, start_pc, next_pc;
+    size_t n_recs;
+};
+bool build_aux_host(const ShardMeta &meta, const std::vector<AluEvent> &alu, const std::vector<MemInitRow> *mem_rows, int exit_code,
+                    const HostPrep &prep, HostTraces *out, std::string *err);
+// the whole shard on the host, cpu chip included (debug C-ABI, tests)
 bool build_traces_host(const Program &prog, const ExecResult &res, size_t shard_pos, const HostPrep &prep, HostTraces *out, std::string *err);
-// Everything of a shard except the cpu trace and the lookups the cpu rows make: mem_init rows, the
-// byte-table multiplicities caused by mem_init, zeroed program/mem_image columns, public values.
-// The device path (K0) adds the cpu chip and its lookup counts on top.
-bool build_aux_host(const Program &prog, const ExecResult &res, size_t shard_pos, const HostPrep &prep, HostTraces *out, std::string *err);
 // instruction index -> row of the program table (provable instructions only; others map to row 0 and never occur)
 std::vector<uint32_t> program_row_map(const Program &prog);
 
 #if defined(__HIPCC__)
-hipError_t launch_k0_cpu_rows(hipStream_t st, const CycleRec *d_recs, size_t n_recs, uint32_t shard, uint32_t pv_end, const Instr *d_instrs,
+hipError_t launch_k0_cpu_rows(hipStream_t st, const CycleRec *d_recs, size_t n_recs, uint32_t shard, uint32_t shard_next_pc, const Instr *d_instrs,
                               const uint32_t *d_prog_row, uint32_t *d_cpu, uint32_t log_n, uint32_t *d_byte_mult, uint32_t *d_prog_mult);
 #endif
 

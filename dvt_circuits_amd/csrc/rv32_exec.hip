@@ -141,130 +141,149 @@ bool load_elf(const uint8_t *elf, size_t n, Program *out, std::string *err) {
 }
 
 // ------------------------------------------------------------------ interpreter
-namespace {
-struct Cell { uint32_t val, ts, sh; uint8_t touched, img; uint32_t init; };
-struct Memory {
-    static constexpr uint32_t PAGE_BITS = 10;
-    std::unordered_map<uint32_t, std::vector<Cell>> pages;
-    Cell &at(uint32_t addr) {  // addr: word-aligned byte address
-        uint32_t w = addr >> 2, pg = w >> PAGE_BITS;
-        auto it = pages.find(pg);
-        if (it == pages.end()) it = pages.emplace(pg, std::vector<Cell>(1u << PAGE_BITS, Cell{0, 0, 0, 0, 0, 0})).first;
-        return it->second[w & ((1u << PAGE_BITS) - 1)];
-    }
-};
-}  // namespace
+static constexpr uint32_t FL_TOUCHED = 1, FL_IMG = 2;
 
-void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin_bufs, bool trace, uint64_t max_cycles,
-             uint32_t log_shard, ExecResult *res) {
-    ExecResult &R = *res;
-    R = ExecResult();
-    Memory mem;  // guest memory, keyed by byte address; registers are kept separately (addresses 0..31 of the AIR)
-    Cell regs[32];
-    for (auto &c : regs) c = Cell{0, 0, 0, 0, 0, 0};
+Vm::Vm(const Program &p, const std::vector<std::vector<uint8_t>> *in, uint32_t ls)
+    : prog(p), pc(p.entry), log_shard(ls), stdin_bufs(in), holders(N_PAGES), raw(N_PAGES, nullptr), own(N_PAGES, 0) {
+    for (auto &c : regs) c = Cell{0, 0, 0, FL_IMG};
     for (auto &kv : prog.image)
-        if (kv.first >= 32) { Cell &c = mem.at(kv.first); c.val = c.init = kv.second; c.img = 1; }
-    size_t next_input = 0;
-    uint32_t pc = prog.entry;
-    const size_t ninstr = prog.instrs.size();
-    const uint64_t shard_cycles = (uint64_t)1 << log_shard;
-    uint32_t shard = 1;   // current shard index (timestamps are (shard, clk))
-    uint32_t in_shard = 0;  // instructions retired in the current shard
-    uint32_t pv_count = 0;  // public-value words committed so far
-    if (trace) { R.shards.emplace_back(); R.shards.back().index = 1; R.shards.back().start_pc = pc; }
-    auto trap = [&](const std::string &m) { R.error = m + " at pc 0x" + [&] { char b[16]; snprintf(b, sizeof b, "%x", pc); return std::string(b); }(); };
-    while (R.cycles < max_cycles) {
-        if (pc < prog.text_base || pc % 4 || (pc - prog.text_base) / 4 >= ninstr) { trap("pc outside text"); return; }
-        if (trace && in_shard == shard_cycles) {  // cut a shard
-            R.shards.back().next_pc = pc;
-            R.shards.back().pv_end = pv_count;
-            shard++;
-            in_shard = 0;
-            R.shards.emplace_back();
-            R.shards.back().index = shard;
-            R.shards.back().start_pc = pc;
-            R.shards.back().pv_start = pv_count;
-        }
-        const uint32_t idx = (pc - prog.text_base) / 4;
-        const Instr &in = prog.instrs[idx];
-        const uint32_t w = in.raw, fl = in.flags;
+        if (kv.first >= 32) { Cell &c = at(kv.first); c.val = kv.second; c.flags = FL_IMG; }
+}
+
+Vm::Vm(const Program &p, const std::vector<std::vector<uint8_t>> *in, uint32_t ls, const Snapshot &s)
+    : prog(p), pc(s.pc), shard(s.shard), log_shard(ls), cycles(s.cycles), collect_output(false), stdin_bufs(in), next_input(s.next_input),
+      holders(N_PAGES), raw(N_PAGES, nullptr), own(N_PAGES, 0) {
+    for (int i = 0; i < 32; i++) regs[i] = s.regs[i];
+    for (auto &kv : s.pages) { holders[kv.first] = kv.second; raw[kv.first] = kv.second.get(); alloc_pages.push_back(kv.first); }
+}
+
+void Vm::make_own(uint32_t pg) {
+    std::shared_ptr<Page> np;
+    if (holders[pg]) np = std::make_shared<Page>(*holders[pg]);   // shared with a snapshot: copy on first access
+    else { np = std::make_shared<Page>(); memset(np.get(), 0, sizeof(Page)); alloc_pages.push_back(pg); }
+    holders[pg] = np;
+    raw[pg] = np.get();
+    own[pg] = 1;
+    owned_pages.push_back(pg);
+}
+
+Snapshot Vm::snapshot() {
+    Snapshot s;
+    for (int i = 0; i < 32; i++) s.regs[i] = regs[i];
+    s.pc = pc; s.shard = shard; s.cycles = cycles; s.next_input = next_input;
+    s.pages.reserve(alloc_pages.size());
+    for (uint32_t pg : alloc_pages) s.pages.emplace_back(pg, holders[pg]);
+    for (uint32_t pg : owned_pages) own[pg] = 0;   // from now on shared with the snapshot
+    owned_pages.clear();
+    return s;
+}
+
+void Vm::trap(const std::string &m) {
+    char b[24];
+    snprintf(b, sizeof b, " at pc 0x%x", pc);
+    error = m + b;
+}
+
+bool Vm::next_shard() {
+    if (shard >= MAX_SHARDS) { error = "execution longer than 65535 shards"; return false; }
+    shard++;
+    in_shard = 0;
+    return true;
+}
+
+void Vm::run_shard(bool trace, ShardOut *out, uint64_t max_total_cycles) {
+    const uint64_t left_in_shard = ((uint64_t)1 << log_shard) - in_shard;
+    const uint64_t left_total = max_total_cycles > cycles ? max_total_cycles - cycles : 0;
+    const uint64_t budget = left_in_shard < left_total ? left_in_shard : left_total;
+    if (trace) {
+        out->index = shard;
+        out->start_pc = pc;
+        out->n_recs = 0;
+        out->alu.clear();
+        run<true>(out, budget);
+        out->next_pc = pc;   // 0 after HALT
+    } else {
+        run<false>(nullptr, budget);
+    }
+    if (error.empty() && !halted && cycles >= max_total_cycles) error = "cycle limit reached before HALT";
+}
+
+template <bool TRACE>
+void Vm::run(ShardOut *out, uint64_t budget) {
+    const Instr *const code = prog.instrs.data();
+    const uint32_t ninstr = (uint32_t)prog.instrs.size(), text_base = prog.text_base;
+    const uint32_t sh = shard;
+    CycleRec *recs = TRACE ? out->recs + out->n_recs : nullptr;
+    uint64_t done = 0;
+    uint32_t lpc = pc;
+    constexpr uint32_t MEM_FAMILY = FL(F_LW) | FL(F_SW) | FL(F_LB) | FL(F_LBU) | FL(F_LH) | FL(F_LHU) | FL(F_SB) | FL(F_SH);
+    constexpr uint32_t BRANCHES = FL(F_BEQ) | FL(F_BNE) | FL(F_BLT) | FL(F_BGE) | FL(F_BLTU) | FL(F_BGEU);
+    auto fail = [&](const char *m) { pc = lpc; trap(m); };
+    while (done < budget) {
+        const uint32_t idx = (lpc - text_base) >> 2;
+        if (idx >= ninstr || (lpc & 3) || lpc < text_base) { fail("pc outside text"); break; }
+        const Instr &in = code[idx];
+        const uint32_t fl = in.flags;
         const uint32_t clk = 4 * (in_shard + 1);
-        CycleRec rec{};
-        rec.idx = idx;
-        rec.pv_idx = pv_count;
-        uint32_t next_pc = pc + 4, a = 0, b = 0, c = 0;
-        if (!in.supported) {
-            // executes but cannot be proven: plain interpreter semantics
-            if (!R.unsupported) { char bb[64]; snprintf(bb, sizeof bb, "instruction 0x%08x at pc 0x%x", w, pc); R.unsupported_what = bb; }
-            R.unsupported = true;
-            const uint32_t op = w & 0x7f, rd = bits(w, 11, 7), f3 = bits(w, 14, 12), rs1 = bits(w, 19, 15), rs2 = bits(w, 24, 20), f7 = bits(w, 31, 25);
-            uint32_t x = regs[rs1].val, y = regs[rs2].val, out = 0;
-            bool wr = true;
-            if (op == 0x13 || op == 0x33) {
-                uint32_t sh = (op == 0x13 ? rs2 : y) & 31;
-                if (op == 0x33 && f7 == 0x01) {
-                    int64_t sx = (int32_t)x, sy = (int32_t)y;
-                    switch (f3) {
-                    case 1: out = (uint32_t)((sx * sy) >> 32); break;
-                    case 2: out = (uint32_t)((sx * (int64_t)(uint64_t)y) >> 32); break;
-                    case 4: out = y == 0 ? 0xffffffffu : (x == 0x80000000u && y == 0xffffffffu) ? x : (uint32_t)((int32_t)x / (int32_t)y); break;
-                    case 5: out = y == 0 ? 0xffffffffu : x / y; break;
-                    case 6: out = y == 0 ? x : (x == 0x80000000u && y == 0xffffffffu) ? 0 : (uint32_t)((int32_t)x % (int32_t)y); break;
-                    case 7: out = y == 0 ? x : x % y; break;
-                    default: trap("illegal instruction"); return;
-                    }
-                } else if (f3 == 1) out = x << sh;
-                else if (f3 == 5) out = (bits(w, 30, 30)) ? (uint32_t)((int32_t)x >> sh) : x >> sh;
-                else { trap("illegal instruction"); return; }
-            } else if (op == 0x03 || op == 0x23) {
-                uint32_t addr = x + (op == 0x03 ? sext(bits(w, 31, 20), 12) : sext((bits(w, 31, 25) << 5) | bits(w, 11, 7), 12));
-                if (addr < 32 || addr >= ADDR_LIMIT) { trap("memory access out of range"); return; }
-                Cell &cell = mem.at(addr & ~3u);
-                uint32_t sh = 8 * (addr & 3);
-                if (op == 0x03) {
-                    uint32_t v = cell.val >> sh;
-                    switch (f3) {
-                    case 0: out = sext(v & 0xff, 8); break;
-                    case 1: if (addr & 1) { trap("misaligned load"); return; } out = sext(v & 0xffff, 16); break;
-                    case 4: out = v & 0xff; break;
-                    case 5: if (addr & 1) { trap("misaligned load"); return; } out = v & 0xffff; break;
-                    default: trap("illegal load"); return;
-                    }
-                } else {
-                    wr = false;
-                    if (f3 == 0) cell.val = (cell.val & ~(0xffu << sh)) | ((y & 0xff) << sh);
-                    else if (f3 == 1) { if (addr & 1) { trap("misaligned store"); return; } cell.val = (cell.val & ~(0xffffu << sh)) | ((y & 0xffff) << sh); }
-                    else { trap("illegal store"); return; }
-                }
-            } else if (op == 0x0f) { wr = false; }
-            else { trap("illegal instruction"); return; }
-            if (wr && rd) regs[rd].val = out;
-            pc = next_pc;
-            R.cycles++;
-            in_shard++;
+        if (__builtin_expect(!in.supported, 0)) {
+            // FENCE retires as a no-op (no chip: the run cannot be proven); everything else without a chip is illegal
+            if ((in.raw & 0x7f) != 0x0f) { fail("illegal instruction"); break; }
+            if (!unsupported) { char bb[64]; snprintf(bb, sizeof bb, "instruction 0x%08x at pc 0x%x", in.raw, lpc); unsupported_what = bb; }
+            unsupported = true;
+            if (TRACE) { fail("instruction without a chip in a traced run"); break; }
+            lpc += 4; done++; in_shard++;
             continue;
         }
-        // ---- provable instruction: accesses in port order c (rs2), b (rs1), memory, a (rd)
-        if (fl & FL(F_RS2_EN)) { Cell &r2 = regs[in.rs2]; c = r2.val; rec.pc_ts = r2.ts; rec.pc_sh = r2.sh; r2.ts = clk; r2.sh = shard; r2.touched = 1; }
+        CycleRec rec;
+        uint32_t sha = 0, shb = 0, shc = 0, shm = 0;
+        if (TRACE) { rec.idx = idx; rec.pa_prev = rec.pa_ts = rec.pb_ts = rec.pc_ts = rec.m_prev = rec.m_ts = 0; }
+        uint32_t next_pc = lpc + 4, a = 0, b = 0, c = 0;
+        // ---- accesses in port order: c (rs2) at clk, b (rs1) at clk + 1, memory at clk + 2, a (rd) at clk + 3
+        if (fl & FL(F_RS2_EN)) { Cell &r2 = regs[in.rs2]; c = r2.val; if (TRACE) { rec.pc_ts = r2.ts; shc = r2.sh; } r2.ts = clk; r2.sh = sh; }
         if (fl & FL(F_IMM_C)) c = in.imm;
-        if (fl & FL(F_RS1_EN)) { Cell &r1 = regs[in.rs1]; b = r1.val; rec.pb_ts = r1.ts; rec.pb_sh = r1.sh; r1.ts = clk + 1; r1.sh = shard; r1.touched = 1; }
-        if (fl & (FL(F_ADD))) a = b + c;
+        if (fl & FL(F_RS1_EN)) { Cell &r1 = regs[in.rs1]; b = r1.val; if (TRACE) { rec.pb_ts = r1.ts; shb = r1.sh; } r1.ts = clk + 1; r1.sh = sh; }
+        if (fl & FL(F_ADD)) a = b + c;
+        else if (fl & MEM_FAMILY) {
+            const uint32_t addr = b + in.off;
+            if (addr < 32 || addr >= ADDR_LIMIT) { fail("memory access out of range"); break; }
+            if ((fl & (FL(F_LW) | FL(F_SW))) && (addr & 3)) { fail("misaligned word access"); break; }
+            if ((fl & (FL(F_LH) | FL(F_LHU) | FL(F_SH))) && (addr & 1)) { fail("misaligned halfword access"); break; }
+            Cell &cell = at(addr & ~3u);
+            if (!(cell.flags & (FL_TOUCHED | FL_IMG))) { cell.flags |= FL_TOUCHED; if (collect_output) first_touch.emplace_back(addr & ~3u, cell.val); }
+            if (TRACE) { rec.m_prev = cell.val; rec.m_ts = cell.ts; shm = cell.sh; }
+            const uint32_t sh8 = 8 * (addr & 3);
+            if (fl & FL(F_LW)) a = cell.val;
+            else if (fl & FL(F_SW)) cell.val = c;
+            else if (fl & FL(F_SB)) cell.val = (cell.val & ~(0xffu << sh8)) | ((c & 0xff) << sh8);
+            else if (fl & FL(F_SH)) cell.val = (cell.val & ~(0xffffu << sh8)) | ((c & 0xffff) << sh8);
+            else if (fl & FL(F_LB)) a = sext((cell.val >> sh8) & 0xff, 8);
+            else if (fl & FL(F_LBU)) a = (cell.val >> sh8) & 0xff;
+            else if (fl & FL(F_LH)) a = sext((cell.val >> sh8) & 0xffff, 16);
+            else a = (cell.val >> sh8) & 0xffff;
+            cell.ts = clk + 2;
+            cell.sh = sh;
+        }
+        else if (fl & FL(F_SLTU)) a = b < c;
+        else if (fl & FL(F_MUL)) a = b * c;
+        else if (fl & FL(F_MULHU)) a = (uint32_t)(((uint64_t)b * c) >> 32);
+        else if (fl & BRANCHES) {
+            bool t = (fl & FL(F_BEQ)) ? b == c : (fl & FL(F_BNE)) ? b != c : (fl & FL(F_BLT)) ? (int32_t)b < (int32_t)c
+                   : (fl & FL(F_BGE)) ? (int32_t)b >= (int32_t)c : (fl & FL(F_BLTU)) ? b < c : b >= c;
+            if (t) next_pc = in.tgt;
+        }
         else if (fl & FL(F_SUB)) a = b - c;
         else if (fl & FL(F_AND)) a = b & c;
         else if (fl & FL(F_OR)) a = b | c;
         else if (fl & FL(F_XOR)) a = b ^ c;
         else if (fl & FL(F_SLT)) a = (int32_t)b < (int32_t)c;
-        else if (fl & FL(F_SLTU)) a = b < c;
-        else if (fl & FL(F_MUL)) a = b * c;
-        else if (fl & FL(F_MULHU)) a = (uint32_t)(((uint64_t)b * c) >> 32);
         else if (fl & FL(F_LUI)) a = in.imm;
         else if (fl & FL(F_ALU)) {
-            const uint32_t sh = c & 31;
+            const uint32_t s5 = c & 31;
             const int32_t sb = (int32_t)b, sc = (int32_t)c;
             switch (in.alu_op) {
-            case ALU_SLL: a = b << sh; break;
-            case ALU_SRL: a = b >> sh; break;
-            case ALU_SRA: a = (uint32_t)(sb >> sh); break;
+            case ALU_SLL: a = b << s5; break;
+            case ALU_SRL: a = b >> s5; break;
+            case ALU_SRA: a = (uint32_t)(sb >> s5); break;
             case ALU_MULH: a = (uint32_t)(((int64_t)sb * (int64_t)sc) >> 32); break;
             case ALU_MULHSU: a = (uint32_t)(((int64_t)sb * (int64_t)(uint64_t)c) >> 32); break;
             // RISC-V: x / 0 = all ones, x % 0 = x; -2^31 / -1 = -2^31 remainder 0
@@ -273,108 +292,122 @@ void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin
             case ALU_REM: a = c == 0 ? b : (b == 0x80000000u && c == 0xffffffffu) ? 0u : (uint32_t)(sb % sc); break;
             default: a = c == 0 ? b : b % c; break;  // ALU_REMU
             }
-            if (trace) R.shards.back().alu.push_back(AluEvent{in.alu_op, a, b, c});
+            if (TRACE) out->alu.push_back(AluEvent{in.alu_op, a, b, c});
         }
         else if (fl & FL(F_JAL)) { a = in.imm; next_pc = in.tgt; }
         else if (fl & FL(F_JALR)) {
             a = in.imm;
-            uint32_t t = b + in.off;
-            if (t >= ADDR_LIMIT) { trap("jump target out of range"); return; }
+            const uint32_t t = b + in.off;
+            if (t >= ADDR_LIMIT) { fail("jump target out of range"); break; }
             next_pc = t & ~1u;
-        } else if (fl & (FL(F_BEQ) | FL(F_BNE) | FL(F_BLT) | FL(F_BGE) | FL(F_BLTU) | FL(F_BGEU))) {
-            bool t = (fl & FL(F_BEQ)) ? b == c : (fl & FL(F_BNE)) ? b != c : (fl & FL(F_BLT)) ? (int32_t)b < (int32_t)c
-                   : (fl & FL(F_BGE)) ? (int32_t)b >= (int32_t)c : (fl & FL(F_BLTU)) ? b < c : b >= c;
-            if (t) next_pc = in.tgt;
-        } else if (fl & (FL(F_LW) | FL(F_SW) | FL(F_LB) | FL(F_LBU) | FL(F_LH) | FL(F_LHU) | FL(F_SB) | FL(F_SH))) {
-            const uint32_t addr = b + in.off;
-            if (addr < 32 || addr >= ADDR_LIMIT) { trap("memory access out of range"); return; }
-            if ((fl & (FL(F_LW) | FL(F_SW))) && (addr & 3)) { trap("misaligned word access"); return; }
-            if ((fl & (FL(F_LH) | FL(F_LHU) | FL(F_SH))) && (addr & 1)) { trap("misaligned halfword access"); return; }
-            Cell &cell = mem.at(addr & ~3u);
-            if (!cell.touched) { cell.touched = 1; cell.init = cell.val; }
-            rec.m_prev = cell.val;
-            rec.m_ts = cell.ts;
-            rec.m_sh = cell.sh;
-            const uint32_t sh8 = 8 * (addr & 3);
-            if (fl & FL(F_SW)) cell.val = c;
-            else if (fl & FL(F_SB)) cell.val = (cell.val & ~(0xffu << sh8)) | ((c & 0xff) << sh8);
-            else if (fl & FL(F_SH)) cell.val = (cell.val & ~(0xffffu << sh8)) | ((c & 0xffff) << sh8);
-            else if (fl & FL(F_LW)) a = cell.val;
-            else if (fl & FL(F_LB)) a = sext((cell.val >> sh8) & 0xff, 8);
-            else if (fl & FL(F_LBU)) a = (cell.val >> sh8) & 0xff;
-            else if (fl & FL(F_LH)) a = sext((cell.val >> sh8) & 0xffff, 16);
-            else a = (cell.val >> sh8) & 0xffff;
-            rec.m_val = cell.val;
-            cell.ts = clk + 2;
-            cell.sh = shard;
         } else if (fl & FL(F_ECALL)) {
-            // b = t0 (id), c = a0
-            uint32_t a1 = regs[11].val, a2 = regs[12].val;
+            // b = t0 (id), c = a0; a1 / a2 are read without a port except by COMMIT
+            const uint32_t a1 = regs[11].val, a2 = regs[12].val;
             a = b;  // t0 unchanged unless the call returns a value
+            bool bad = false;
             switch (b) {
-            case 0x00: R.halted = true; R.exit_code = (int)c; next_pc = 0; break;
-            case 0x02: {  // WRITE(fd = a0, ptr = a1, len = a2)
+            case 0x00: halted = true; exit_code = (int)c; next_pc = 0; break;
+            case 0x02: {  // WRITE(fd = a0, ptr = a1, len = a2): fd 3 = the public-value stream
+                if ((uint64_t)a1 + a2 > ADDR_LIMIT) { fail("WRITE buffer out of range"); bad = true; break; }
+                if (!collect_output) break;
+                std::vector<uint8_t> &dst = c == 3 ? public_values : stdout_bytes;
                 for (uint32_t k = 0; k < a2; k++) {
-                    uint32_t ad = a1 + k;
-                    if (ad < 32 || ad >= ADDR_LIMIT) { trap("WRITE buffer out of range"); return; }
-                    uint8_t by = (uint8_t)(mem.at(ad & ~3u).val >> (8 * (ad & 3)));
-                    R.stdout_bytes.push_back(by);  // (fd 3 included: only COMMIT words are public values)
+                    const uint32_t ad = a1 + k;
+                    const Cell *cell = ad >= 32 ? peek(ad & ~3u) : nullptr;
+                    dst.push_back(cell ? (uint8_t)(cell->val >> (8 * (ad & 3))) : 0);
                 }
                 break;
             }
-            case 0x10:  // COMMIT(a0 = word): the next public-value word (bound by the proof)
-                for (int q = 0; q < 4; q++) R.public_values.push_back((uint8_t)(c >> (8 * q)));
-                pv_count++;
+            case SYS_COMMIT: {  // COMMIT(a0 = index, a1 = word): a1 is read through the memory port
+                Cell &r11 = regs[REG_A1];
+                if (TRACE) { rec.m_prev = r11.val; rec.m_ts = r11.ts; shm = r11.sh; }
+                r11.ts = clk + 2;
+                r11.sh = sh;
+                if (c < 8) { committed[c] = a1; committed_mask |= 1u << c; }
                 break;
+            }
             case 0x1a: break;  // COMMIT_DEFERRED_PROOFS: no-op (no recursion in core proofs)
-            case 0xf0: a = next_input < stdin_bufs.size() ? (uint32_t)stdin_bufs[next_input].size() : 0; break;
+            case 0xf0: a = next_input < stdin_bufs->size() ? (uint32_t)(*stdin_bufs)[next_input].size() : 0; break;
             case 0xf1: {  // HINT_READ(ptr = a0, len = a1): the words become initial memory (must be untouched so far)
-                if (next_input >= stdin_bufs.size()) { trap("HINT_READ with no input left"); return; }
-                const auto &buf = stdin_bufs[next_input++];
-                if (a1 != buf.size()) { trap("HINT_READ length mismatch"); return; }
-                if (c % 4 || c < 32 || (uint64_t)c + a1 > ADDR_LIMIT) { trap("HINT_READ pointer misaligned or out of range"); return; }
+                if (next_input >= stdin_bufs->size()) { fail("HINT_READ with no input left"); bad = true; break; }
+                const auto &buf = (*stdin_bufs)[next_input++];
+                if (a1 != buf.size()) { fail("HINT_READ length mismatch"); bad = true; break; }
+                if (c % 4 || c < 32 || (uint64_t)c + a1 > ADDR_LIMIT) { fail("HINT_READ pointer misaligned or out of range"); bad = true; break; }
                 for (uint32_t k = 0; k < a1; k += 4) {
-                    Cell &cell = mem.at(c + k);
-                    if (cell.touched || cell.sh || cell.img) { trap("HINT_READ into the program image or into memory that was already accessed"); return; }
+                    Cell &cell = at(c + k);
+                    if (cell.flags || cell.sh) { fail("HINT_READ into the program image or into memory that was already accessed"); bad = true; break; }
                     uint32_t wv = 0;
                     for (uint32_t q = 0; q < 4 && k + q < a1; q++) wv |= (uint32_t)buf[k + q] << (8 * q);
                     cell.val = wv;
                 }
                 break;
             }
-            default: trap("unknown syscall"); return;
+            default: fail("unknown syscall"); bad = true; break;
             }
+            if (bad) break;
         }
-        if (fl & FL(F_RD_EN)) { Cell &rdc = regs[in.rd]; rec.pa_prev = rdc.val; rec.pa_ts = rdc.ts; rec.pa_sh = rdc.sh; rdc.val = a; rdc.ts = clk + 3; rdc.sh = shard; rdc.touched = 1; }
-        rec.a = a; rec.b = b; rec.c = c; rec.next_pc = next_pc;
-        if (trace) R.shards.back().recs.push_back(rec);
-        R.cycles++;
+        if (fl & FL(F_RD_EN)) { Cell &rdc = regs[in.rd]; if (TRACE) { rec.pa_prev = rdc.val; rec.pa_ts = rdc.ts; sha = rdc.sh; } rdc.val = a; rdc.ts = clk + 3; rdc.sh = sh; }
+        if (TRACE) {
+            rec.a = a; rec.b = b; rec.c = c;
+            rec.sh_ab = sha | (shb << 16);
+            rec.sh_cm = shc | (shm << 16);
+            recs[done] = rec;
+        }
+        done++;
         in_shard++;
-        pc = next_pc;
-        if (R.halted) break;
+        lpc = next_pc;
+        if (halted) break;
     }
-    if (!R.halted && R.error.empty()) R.error = "cycle limit reached before HALT";
-    if (trace) {
-        R.shards.back().next_pc = pc;  // 0 after HALT
-        R.shards.back().pv_end = pv_count;
-        // one mem_init row per image word and per touched non-image word, sorted by address
-        std::map<uint32_t, MemInitRow> rows;
-        for (auto &kv : prog.image) {
-            MemInitRow r{kv.first, kv.second, kv.second, 0, 0, 1};
-            if (kv.first < 32) { r.f = regs[kv.first].val; r.fts = regs[kv.first].ts; r.fsh = regs[kv.first].sh; }
-            rows[kv.first] = r;
+    if (error.empty()) pc = lpc;
+    cycles += done;
+    if (TRACE) out->n_recs += done;
+}
+
+std::vector<MemInitRow> Vm::mem_rows() const {
+    std::vector<MemInitRow> rows;
+    rows.reserve(prog.image.size() + first_touch.size());
+    for (auto &kv : prog.image) {
+        MemInitRow r{kv.first, kv.second, kv.second, 0, 0, 1};
+        const Cell *c = kv.first < 32 ? &regs[kv.first] : peek(kv.first);
+        if (c && c->sh) { r.f = c->val; r.fts = c->ts; r.fsh = c->sh; }
+        rows.push_back(r);
+    }
+    for (auto &ft : first_touch) {
+        const Cell *c = peek(ft.first);
+        rows.push_back(MemInitRow{ft.first, ft.second, c->val, c->ts, c->sh, 0});
+    }
+    std::sort(rows.begin(), rows.end(), [](const MemInitRow &x, const MemInitRow &y) { return x.addr < y.addr; });
+    return rows;
+}
+
+void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin_bufs, bool trace, uint64_t max_cycles,
+             uint32_t log_shard, ExecResult *res) {
+    ExecResult &R = *res;
+    R = ExecResult();
+    Vm vm(prog, &stdin_bufs, log_shard);
+    ShardOut out;
+    std::vector<CycleRec> buf;
+    if (trace) buf.resize((size_t)1 << log_shard);
+    out.recs = buf.data();
+    for (;;) {
+        vm.run_shard(trace, &out, max_cycles);
+        if (trace && vm.error.empty()) {
+            R.shards.emplace_back();
+            ShardRec &S = R.shards.back();
+            S.index = out.index; S.start_pc = out.start_pc; S.next_pc = out.next_pc;
+            S.recs.assign(out.recs, out.recs + out.n_recs);
+            S.alu = out.alu;
         }
-        for (auto &pg : mem.pages)
-            for (uint32_t k = 0; k < (1u << Memory::PAGE_BITS); k++) {
-                const Cell &cell = pg.second[k];
-                uint32_t addr = ((pg.first << Memory::PAGE_BITS) | k) << 2;
-                auto it = rows.find(addr);
-                if (it != rows.end()) {
-                    if (cell.touched) { it->second.f = cell.val; it->second.fts = cell.ts; it->second.fsh = cell.sh; }
-                } else if (cell.touched) rows[addr] = MemInitRow{addr, cell.init, cell.val, cell.ts, cell.sh, 0};
-            }
-        for (auto &kv : rows) R.mem_rows.push_back(kv.second);
+        if (vm.halted || !vm.error.empty()) break;
+        if (!vm.next_shard()) break;
     }
+    R.exit_code = vm.exit_code; R.halted = vm.halted; R.cycles = vm.cycles;
+    R.unsupported = vm.unsupported; R.unsupported_what = vm.unsupported_what;
+    R.public_values = std::move(vm.public_values); R.stdout_bytes = std::move(vm.stdout_bytes);
+    for (int i = 0; i < 8; i++) R.committed[i] = vm.committed[i];
+    R.committed_mask = vm.committed_mask;
+    R.error = vm.error;
+    if (trace && vm.halted) R.mem_rows = vm.mem_rows();
 }
 
 // ------------------------------------------------------------------ preprocessed traces
@@ -445,13 +478,12 @@ std::vector<uint32_t> program_row_map(const Program &prog) {
     return m;
 }
 
-bool build_aux_host(const Program &prog, const ExecResult &res, size_t shard_pos, const HostPrep &prep, HostTraces *out, std::string *err) {
+bool build_aux_host(const ShardMeta &S, const std::vector<AluEvent> &alu, const std::vector<MemInitRow> *mem_rows, int exit_code,
+                    const HostPrep &prep, HostTraces *out, std::string *err) {
     HostTraces &T = *out;
-    if (shard_pos >= res.shards.size() || res.shards[shard_pos].recs.empty()) { if (err) *err = "no cycles to prove"; return false; }
-    if (res.unsupported) { if (err) *err = "unsupported " + res.unsupported_what; return false; }
-    const ShardRec &S = res.shards[shard_pos];
-    const bool last = shard_pos + 1 == res.shards.size();
-    const uint32_t lc = ceil_log2(S.recs.size());
+    if (S.n_recs == 0) { if (err) *err = "no cycles to prove"; return false; }
+    const bool last = mem_rows != nullptr;
+    const uint32_t lc = ceil_log2(S.n_recs);
     if (lc > 22) { if (err) *err = "shard longer than 2^22 cycles"; return false; }
     for (int c = 0; c < N_CHIPS; c++) { T.present[c] = true; T.main[c].clear(); }
     T.log_n[RV32_CHIP_CPU] = lc;
@@ -460,26 +492,29 @@ bool build_aux_host(const Program &prog, const ExecResult &res, size_t shard_pos
     T.present[RV32_CHIP_MEM_INIT] = last;
     T.log_n[RV32_CHIP_MEM_INIT] = 0;
     if (last) {
-        const uint32_t lm = ceil_log2(res.mem_rows.size());
+        const uint32_t lm = ceil_log2(mem_rows->size());
         const size_t nm = (size_t)1 << lm;
         T.log_n[RV32_CHIP_MEM_INIT] = lm;
         auto &M = T.main[RV32_CHIP_MEM_INIT];
         M.assign((size_t)RV32_MEM_INIT_MAIN_W * nm, 0);
         uint32_t prev_addr = 0;
-        for (size_t r = 0; r < res.mem_rows.size(); r++) {
-            const MemInitRow &m = res.mem_rows[r];
+        for (size_t r = 0; r < mem_rows->size(); r++) {
+            const MemInitRow &m = (*mem_rows)[r];
             auto put = [&](int col, uint32_t v) { M[(size_t)col * nm + r] = v; };
-            put(RV32_MEM_INIT_addr, m.addr); put(RV32_MEM_INIT_fts, m.fts); put(RV32_MEM_INIT_fsh, m.fsh);
+            put(RV32_MEM_INIT_fts, m.fts); put(RV32_MEM_INIT_fsh, m.fsh);
             put(RV32_MEM_INIT_is_img, m.is_img); put(RV32_MEM_INIT_is_real, 1);
             uint32_t d = r ? m.addr - prev_addr - 1 : 0;
             for (int i = 0; i < 4; i++) {
+                put(RV32_MEM_INIT_ab_0 + i, (m.addr >> (8 * i)) & 0xff);
                 put(RV32_MEM_INIT_v_0 + i, (m.v >> (8 * i)) & 0xff);
                 put(RV32_MEM_INIT_f_0 + i, (m.f >> (8 * i)) & 0xff);
                 put(RV32_MEM_INIT_d_0 + i, (d >> (8 * i)) & 0xff);
             }
-            sink.byte(B_RANGE - 1, ((d & 0xff) << 8) | ((d >> 8) & 0xff));
-            sink.byte(B_RANGE - 1, (((d >> 16) & 0xff) << 8) | (d >> 24));
-            sink.byte(B_LTU - 1, ((d >> 24) << 8) | 0x40);
+            for (uint32_t w : {m.addr, d}) {
+                sink.byte(B_RANGE - 1, ((w & 0xff) << 8) | ((w >> 8) & 0xff));
+                sink.byte(B_RANGE - 1, (((w >> 16) & 0xff) << 8) | (w >> 24));
+                sink.byte(B_LTU - 1, ((w >> 24) << 8) | (ADDR_LIMIT >> 24));
+            }
             if (!m.is_img) {
                 sink.byte(B_RANGE - 1, ((m.v & 0xff) << 8) | ((m.v >> 8) & 0xff));
                 sink.byte(B_RANGE - 1, (((m.v >> 16) & 0xff) << 8) | (m.v >> 24));
@@ -489,7 +524,7 @@ bool build_aux_host(const Program &prog, const ExecResult &res, size_t shard_pos
     }
     // shift chip: one row per SLL/SRL/SRA of this shard (absent when the shard does not shift)
     std::vector<AluEvent> shifts, muldivs;
-    for (auto &e : S.alu) (e.op <= ALU_SRA ? shifts : muldivs).push_back(e);
+    for (auto &e : alu) (e.op <= ALU_SRA ? shifts : muldivs).push_back(e);
     T.present[RV32_CHIP_SHIFT] = !shifts.empty();
     T.log_n[RV32_CHIP_SHIFT] = 0;
     if (!shifts.empty()) {
@@ -628,23 +663,26 @@ bool build_aux_host(const Program &prog, const ExecResult &res, size_t shard_pos
     T.main[RV32_CHIP_BYTE] = byte_mult;  // [7][65536] already column-major in op order
     T.log_n[RV32_CHIP_MEM_IMAGE] = prep.log_n[RV32_CHIP_MEM_IMAGE];
     T.main[RV32_CHIP_MEM_IMAGE].assign((size_t)1 << T.log_n[RV32_CHIP_MEM_IMAGE], 0);
-    T.pubs = {S.start_pc % P, S.next_pc % P, last ? (uint32_t)res.exit_code % P : 0u, S.index, last ? 1u : 0u, S.pv_start, S.pv_end};
+    T.pubs = {S.start_pc % P, S.next_pc % P, last ? (uint32_t)exit_code % P : 0u, S.index, last ? 1u : 0u};
     return true;
 }
 
 bool build_traces_host(const Program &prog, const ExecResult &res, size_t shard_pos, const HostPrep &prep, HostTraces *out, std::string *err) {
     HostTraces &T = *out;
-    if (!build_aux_host(prog, res, shard_pos, prep, out, err)) return false;
+    if (shard_pos >= res.shards.size()) { if (err) *err = "no such shard"; return false; }
+    if (res.unsupported) { if (err) *err = "unsupported " + res.unsupported_what; return false; }
     const ShardRec &S = res.shards[shard_pos];
+    const bool last = shard_pos + 1 == res.shards.size();
+    if (!build_aux_host(ShardMeta{S.index, S.start_pc, S.next_pc, S.recs.size()}, S.alu, last ? &res.mem_rows : nullptr, res.exit_code, prep, out, err)) return false;
     const size_t nc = (size_t)1 << T.log_n[RV32_CHIP_CPU];
     T.main[RV32_CHIP_CPU].assign((size_t)RV32_CPU_MAIN_W * nc, 0);
     std::vector<uint32_t> prog_idx_mult(prog.instrs.size(), 0);
     HostSink sink{T.main[RV32_CHIP_CPU].data(), nc, 0, T.main[RV32_CHIP_BYTE].data(), prog_idx_mult.data()};
     for (size_t r = 0; r < S.recs.size(); r++) {
         sink.row = r;
-        fill_cpu_row(S.recs[r], prog.instrs[S.recs[r].idx], (uint32_t)r, S.index, sink);
+        const uint32_t next_pc = r + 1 < S.recs.size() ? prog.instrs[S.recs[r + 1].idx].pc : S.next_pc;
+        fill_cpu_row(S.recs[r], prog.instrs[S.recs[r].idx], (uint32_t)r, S.index, next_pc, sink);
     }
-    for (size_t r = S.recs.size(); r < nc; r++) T.main[RV32_CHIP_CPU][(size_t)RV32_CPU_pv_idx * nc + r] = S.pv_end;
     // program multiplicities follow the preprocessed row order (provable instructions only)
     std::vector<uint32_t> rowmap = program_row_map(prog);
     for (size_t i = 0; i < prog.instrs.size(); i++)

@@ -1,12 +1,12 @@
 // K0 — trace generation on the GPU.
 //
-// The host executor uploads one compact 68-byte record per retired instruction;
-// one thread expands one record into the 104 columns of the cpu chip (byte limbs,
+// The host executor uploads one compact 48-byte record per retired instruction;
+// one thread expands one record into the 103 columns of the cpu chip (byte limbs,
 // carries, comparator flags, product bytes, ...) and counts its table lookups in
 // the byte-table and program-table multiplicity columns.
 // Column-major output: the 64 lanes of a wave write 64 consecutive rows of a
 // column, so every store is a coalesced 256-B request.  HBM-write bound
-// (4 B x 104 columns per cycle against 68 B read).
+// (4 B x 103 columns per cycle against 48 B read).
 //
 // Lookup counting: a few table rows are extremely hot (the high limbs of the
 // timestamp differences are almost always (0,0); loop bodies hit the same dozen
@@ -62,7 +62,7 @@ struct DeviceSink {
     __device__ void prog(uint32_t idx) { count(K0_PROG_KEY_BASE + prog_row[idx]); }
 };
 
-__global__ void __launch_bounds__(256) k0_cpu_rows_kernel(const CycleRec *recs, size_t n_recs, uint32_t shard, uint32_t pv_end, const Instr *instrs, const uint32_t *prog_row,
+__global__ void __launch_bounds__(256) k0_cpu_rows_kernel(const CycleRec *recs, size_t n_recs, uint32_t shard, uint32_t shard_next_pc, const Instr *instrs, const uint32_t *prog_row,
                                                          uint32_t *cpu, uint32_t log_n, uint32_t *byte_mult, uint32_t *prog_mult) {
     __shared__ uint32_t keys[K0_SLOTS], counts[K0_SLOTS];
     for (uint32_t s = threadIdx.x; s < K0_SLOTS; s += blockDim.x) { keys[s] = K0_EMPTY; counts[s] = 0; }
@@ -74,24 +74,22 @@ __global__ void __launch_bounds__(256) k0_cpu_rows_kernel(const CycleRec *recs, 
         if (r < n_recs) {
             const CycleRec rec = recs[r];
             const Instr in = instrs[rec.idx];
+            const uint32_t next_pc = r + 1 < n_recs ? instrs[recs[r + 1].idx].pc : shard_next_pc;
             sink.row = r;
-            fill_cpu_row(rec, in, (uint32_t)r, shard, sink);
-        } else if (r < sink.n) {
-            sink.row = r;
-            sink.put(RV32_CPU_pv_idx, pv_end);   // padding rows keep the running count of committed words
-        }
+            fill_cpu_row(rec, in, (uint32_t)r, shard, next_pc, sink);
+        }   // (padding rows stay all-zero: the launch wrapper cleared the matrix)
     }
     __syncthreads();
     for (uint32_t s = threadIdx.x; s < K0_SLOTS; s += blockDim.x)
         if (keys[s] != K0_EMPTY && counts[s]) sink.global_add(keys[s], counts[s]);
 }
 
-hipError_t launch_k0_cpu_rows(hipStream_t st, const CycleRec *d_recs, size_t n_recs, uint32_t shard, uint32_t pv_end, const Instr *d_instrs,
+hipError_t launch_k0_cpu_rows(hipStream_t st, const CycleRec *d_recs, size_t n_recs, uint32_t shard, uint32_t shard_next_pc, const Instr *d_instrs,
                               const uint32_t *d_prog_row, uint32_t *d_cpu, uint32_t log_n, uint32_t *d_byte_mult, uint32_t *d_prog_mult) {
     hipError_t e = hipMemsetAsync(d_cpu, 0, ((size_t)RV32_CPU_MAIN_W << log_n) * 4, st);
     if (e != hipSuccess) return e;
     unsigned blocks = (unsigned)((((size_t)1 << log_n) + K0_ROWS_PER_BLOCK - 1) / K0_ROWS_PER_BLOCK);
-    k0_cpu_rows_kernel<<<blocks, 256, 0, st>>>(d_recs, n_recs, shard, pv_end, d_instrs, d_prog_row, d_cpu, log_n, d_byte_mult, d_prog_mult);
+    k0_cpu_rows_kernel<<<blocks, 256, 0, st>>>(d_recs, n_recs, shard, shard_next_pc, d_instrs, d_prog_row, d_cpu, log_n, d_byte_mult, d_prog_mult);
     return hipGetLastError();
 }
 

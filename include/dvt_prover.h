@@ -46,7 +46,8 @@ typedef struct dvt_pk dvt_pk;
 /* ---------------------------------------------------------------- lifecycle */
 /* ProverClient::from_env() (src/main.rs:438,461,481).  cfg_json may be NULL or
  * a JSON object: {"device":0,"fri_queries":100,"pow_bits":16,"profile":0,"log_shard_size":21,
- * "keep_phase1":1}.  keep_phase1 = 0 makes phase 2 of a shard recompute K0 and the main-trace commitment
+ * "keep_phase1":1,"exec_threads":0}.  exec_threads = trace-mode executor threads of the prove pipeline
+ * (0 = from the host's core count).  keep_phase1 = 0 makes phase 2 of a shard recompute K0 and the main-trace commitment
  * instead of keeping them in HBM (about 3 GB per 2^21-cycle shard) between the two phases. */
 int dvt_prover_create(const char *cfg_json, dvt_prover **out);
 void dvt_prover_destroy(dvt_prover *p);
@@ -144,22 +145,37 @@ typedef struct {
 int dvt_setup(dvt_prover *p, const uint8_t *elf, size_t elf_len, dvt_pk **pk, uint8_t **vk, size_t *vk_len);
 /* client.execute(elf,&stdin).run() (src/main.rs:439-442,498-501): host-only emulation.
  * Returns DVT_ERR_GUEST when the guest halts with a non-zero exit code or traps
- * (the reference maps both to process exit code 1).  *public_values = bytes the
- * guest wrote to fd 3; *err_text (optional) = trap reason; both via dvt_free. */
+ * (the reference maps both to process exit code 1).  *public_values = the bytes the
+ * guest wrote to fd 3 with the WRITE syscall (sp1_zkvm::io::commit, reference
+ * crates/finalization_prove/src/main.rs:26-32), i.e. what SP1PublicValues holds;
+ * *err_text (optional) = trap reason; both via dvt_free.
+ * Guest syscall ABI (SP1's): t0 = id, a0..a2 = arguments: 0x00 HALT(code),
+ * 0x02 WRITE(fd, ptr, len), 0x10 COMMIT(index, word) - the eight words of SHA-256(public-value bytes),
+ * which the proof binds -, 0x1A COMMIT_DEFERRED_PROOFS (no-op), 0xF0 HINT_LEN, 0xF1 HINT_READ(ptr, len).
+ * Precompile syscalls (SHA-256 / BLS12-381 / secp256k1 accelerators) are not implemented: the guest traps. */
 int dvt_execute(const uint8_t *elf, size_t elf_len, const dvt_buf *stdin_bufs, size_t nbuf, uint64_t max_cycles,
                 uint8_t **public_values, size_t *pv_len, dvt_report *report, char **err_text);
+/* the same, also handing back what the guest wrote to the other file descriptors (SP1 forwards fd 1 / 2 to the
+ * host's stdout / stderr while executing) */
+int dvt_execute_io(const uint8_t *elf, size_t elf_len, const dvt_buf *stdin_bufs, size_t nbuf, uint64_t max_cycles,
+                   uint8_t **public_values, size_t *pv_len, uint8_t **stdout_bytes, size_t *stdout_len,
+                   dvt_report *report, char **err_text);
 /* client.prove(&pk,&stdin).run() (src/main.rs:463-466), SP1 "core" mode: execute,
  * generate traces, prove on the GPU.  The returned bytes are what proof.save(path)
  * (src/main.rs:472-474) would write. */
 int dvt_prove_core(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_bufs, size_t nbuf, uint8_t **proof,
                    size_t *proof_len, dvt_report *report);
-/* dvt_prove_core in pieces, so that callers (and bench.py) can keep an execution resident in HBM and
- * spread its shards over several GPUs.  An execution is cut into shards of 2^log_shard_size cycles
- * (cfg "log_shard_size", default 21).  All shards are proven with COMMON LogUp challenges derived
- * from every shard's 15-word header (main-trace Merkle root + 7 public values), which is the one
- * exchange step of the path (an all-gather of 60 bytes per shard):
- *   prepare        host execution + upload of the compact per-cycle records and auxiliary traces
- *   commit_shard   phase 1 of shard i: K0 + K1..K3 of the main traces -> header
+/* dvt_prove_core in pieces, so that callers (and bench.py) can spread the shards of one execution over
+ * several GPUs.  An execution is cut into shards of 2^log_shard_size cycles (cfg "log_shard_size",
+ * default 21).  All shards are proven with COMMON LogUp challenges derived from every shard's header
+ * (dvt_rv32_header_words() = 13 words: main-trace Merkle root + 5 public values), which is the one
+ * exchange step of the path (an all-gather of 52 bytes per shard):
+ *   prepare        the executor pipeline: one sequential fast pass of the guest cuts the execution into
+ *                  shards; the shards this job owns (prepare: all; prepare_part: first, first + stride, ...)
+ *                  are re-executed in trace mode on host threads, uploaded (compact 48-byte per-cycle
+ *                  records) and taken through phase 1 on the GPU as they arrive
+ *   commit_shard   header of shard i (global position in the execution); phase 1 = K0 + K1..K3 of the
+ *                  main traces runs here only if the pipeline's result has been consumed by an earlier proof
  *   challenges     host-only: the common challenges from ALL headers (in shard order)
  *   prove_shard    phase 2 of shard i: K0..K9 with those challenges -> shard proof bytes
  *   assemble       container (what proof.save would write) from the shard proofs, in order
@@ -167,10 +183,17 @@ int dvt_prove_core(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_bufs, s
 typedef struct dvt_job dvt_job;
 int dvt_rv32_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_bufs, size_t nbuf, dvt_job **job,
                      dvt_report *report);
+int dvt_rv32_prepare_part(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_bufs, size_t nbuf, size_t first,
+                          size_t stride, dvt_job **job, dvt_report *report);
+/* words per shard header (13) */
+uint32_t dvt_rv32_header_words(void);
+/* seconds the GPU-side thread of the last prepare spent waiting for the host executor (0 = fully hidden) */
+double dvt_rv32_job_exec_wait_seconds(const dvt_job *job);
 int dvt_rv32_prove_job(dvt_prover *p, const dvt_pk *pk, dvt_job *job, uint8_t **proof, size_t *proof_len);
 void dvt_job_free(dvt_prover *p, dvt_job *job);
+/* shards of the whole execution (a prepare_part job holds only its share of them) */
 size_t dvt_rv32_job_shards(const dvt_job *job);
-int dvt_rv32_commit_shard(dvt_prover *p, const dvt_pk *pk, dvt_job *job, size_t shard, uint32_t header[15]);
+int dvt_rv32_commit_shard(dvt_prover *p, const dvt_pk *pk, dvt_job *job, size_t shard, uint32_t *header);
 int dvt_rv32_challenges(const uint8_t *vk, size_t vk_len, const uint32_t *headers, size_t n_shards, uint32_t out[8]);
 int dvt_rv32_prove_shard(dvt_prover *p, const dvt_pk *pk, dvt_job *job, size_t shard, const uint32_t challenges[8],
                          uint8_t **proof, size_t *proof_len);
@@ -181,7 +204,10 @@ int dvt_rv32_assemble(const dvt_job *job, const uint8_t *const *shard_proofs, co
 int dvt_rv32_debug_device_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *job, size_t shard, uint32_t **blob,
                                  size_t *blob_words);
 /* stock `client.verify(&proof,&vk)` semantics (NOT the reference's re-execution
- * `verify` sub-command).  Host-only. */
+ * `verify` sub-command).  Host-only.  *public_values = the guest's fd-3 byte
+ * stream; the proof binds it through the eight COMMITted words of its SHA-256 digest, which the
+ * verifier recomputes.  fri_queries / pow_bits are the parameters the CALLER accepts
+ * (1..1024 queries, at most 30 bits; anything else is DVT_ERR_INPUT). */
 int dvt_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, size_t proof_len, uint32_t fri_queries,
                uint32_t pow_bits, int32_t *exit_code, uint8_t **public_values, size_t *pv_len, char **reason);
 /* test hook, host only: FP64 formulation of Poseidon2 (csrc/poseidon2_f64.cuh, what the hashing kernels run)

@@ -11,26 +11,232 @@ M32 = 0xFFFFFFFF
 HEAP = 0x00400000
 
 
-def _write_pv(a, ptr_reg, nbytes):
-    """commit nbytes/4 words starting at ptr_reg as public values (one COMMIT ecall per word)"""
+SHA_K = [
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2]
+SHA_H0 = [0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19]
+
+
+def sha_padding(nbytes):
+    """the SHA-256 padding of an nbytes-long message (nbytes % 4 == 0) as little-endian memory words"""
     assert nbytes % 4 == 0
-    lab = f"commit_{len(a.items)}"
+    pad = b"\x80" + b"\0" * ((55 - nbytes) % 64) + (8 * nbytes).to_bytes(8, "big")
+    assert (nbytes + len(pad)) % 64 == 0
+    return [w for (w,) in struct.iter_unpack("<I", pad)]
+
+
+def emit_sha256(a):
+    """SHA-256 compression in RV32IM: label `sha256_blocks`(a0 = message, already padded, a1 = number of 64-byte blocks,
+    a2 = the eight state words, updated in place).  Clobbers every t, a and s register except ra / sp.  Emitted once
+    per program; its tables live in the data segment."""
+    if "sha256_blocks" in a.labels or getattr(a, "_sha_pending", False):
+        return
+    a._sha_pending = True
+    ktab = a.dword("sha_k", SHA_K)
+    wtab = a.dword("sha_w", [0] * 64)
+    st = ["a3", "a4", "a5", "a6", "a7", "t3", "t4", "t5"]   # a b c d e f g h
+
+    def rotr(dst, src, n, tmp):
+        a.srli(dst, src, n)
+        a.slli(tmp, src, 32 - n)
+        a.or_(dst, dst, tmp)
+
+    a.j("sha256_end")
+    a.label("sha256_blocks")
+    a.mv("s0", "a0")
+    a.mv("s1", "a1")
+    a.mv("s2", "a2")
+    a.li("s3", wtab)
+    a.li("s4", ktab)
+    a.label("sha_block")
+    # message schedule: W[0..15] = big-endian words of the block
+    a.li("s5", 0)
+    a.li("s6", 64)
+    a.label("sha_ld")
+    a.add("t6", "s0", "s5")
+    a.lbu("t0", "t6", 0)
+    a.slli("t0", "t0", 24)
+    a.lbu("t1", "t6", 1)
+    a.slli("t1", "t1", 16)
+    a.or_("t0", "t0", "t1")
+    a.lbu("t1", "t6", 2)
+    a.slli("t1", "t1", 8)
+    a.or_("t0", "t0", "t1")
+    a.lbu("t1", "t6", 3)
+    a.or_("t0", "t0", "t1")
+    a.add("t6", "s3", "s5")
+    a.sw("t0", "t6", 0)
+    a.addi("s5", "s5", 4)
+    a.bne("s5", "s6", "sha_ld")
+    a.li("s6", 256)
+    a.label("sha_ext")          # W[i] = W[i-16] + s0(W[i-15]) + W[i-7] + s1(W[i-2])
+    a.add("t6", "s3", "s5")
+    a.lw("t0", "t6", -60)
+    rotr("t1", "t0", 7, "t2")
+    rotr("s7", "t0", 18, "t2")
+    a.xor("t1", "t1", "s7")
+    a.srli("s7", "t0", 3)
+    a.xor("t1", "t1", "s7")
+    a.lw("t0", "t6", -8)
+    rotr("s7", "t0", 17, "t2")
+    rotr("s8", "t0", 19, "t2")
+    a.xor("s7", "s7", "s8")
+    a.srli("s8", "t0", 10)
+    a.xor("s7", "s7", "s8")
+    a.add("t1", "t1", "s7")
+    a.lw("t0", "t6", -64)
+    a.add("t1", "t1", "t0")
+    a.lw("t0", "t6", -28)
+    a.add("t1", "t1", "t0")
+    a.sw("t1", "t6", 0)
+    a.addi("s5", "s5", 4)
+    a.bne("s5", "s6", "sha_ext")
+    for k, r_ in enumerate(st):
+        a.lw(r_, "s2", 4 * k)
+    A, B, Cc, D, E, F, G, H = st
+    a.li("s5", 0)
+    a.label("sha_round")
+    rotr("t0", E, 6, "t2")
+    rotr("t1", E, 11, "t2")
+    a.xor("t0", "t0", "t1")
+    rotr("t1", E, 25, "t2")
+    a.xor("t0", "t0", "t1")        # S1
+    a.and_("t1", E, F)
+    a.xori("t2", E, -1)
+    a.and_("t2", "t2", G)
+    a.xor("t1", "t1", "t2")        # ch
+    a.add("t0", "t0", "t1")
+    a.add("t0", "t0", H)
+    a.add("t6", "s4", "s5")
+    a.lw("t1", "t6", 0)
+    a.add("t0", "t0", "t1")
+    a.add("t6", "s3", "s5")
+    a.lw("t1", "t6", 0)
+    a.add("t0", "t0", "t1")        # T1
+    rotr("t1", A, 2, "t2")
+    rotr("t6", A, 13, "t2")
+    a.xor("t1", "t1", "t6")
+    rotr("t6", A, 22, "t2")
+    a.xor("t1", "t1", "t6")        # S0
+    a.and_("t2", A, B)
+    a.and_("t6", A, Cc)
+    a.xor("t2", "t2", "t6")
+    a.and_("t6", B, Cc)
+    a.xor("t2", "t2", "t6")        # maj
+    a.add("t1", "t1", "t2")        # T2
+    a.mv(H, G)
+    a.mv(G, F)
+    a.mv(F, E)
+    a.add(E, D, "t0")
+    a.mv(D, Cc)
+    a.mv(Cc, B)
+    a.mv(B, A)
+    a.add(A, "t0", "t1")
+    a.addi("s5", "s5", 4)
+    a.bne("s5", "s6", "sha_round")
+    for k, r_ in enumerate(st):
+        a.lw("t0", "s2", 4 * k)
+        a.add("t0", "t0", r_)
+        a.sw("t0", "s2", 4 * k)
+    a.addi("s0", "s0", 64)
+    a.addi("s1", "s1", -1)
+    a.bne("s1", "zero", "sha_block")
+    a.ret()
+    a.label("sha256_end")
+
+
+def _bswap(a, dst, src, t1, t2):
+    a.slli(dst, src, 24)
+    a.srli(t1, src, 24)
+    a.or_(dst, dst, t1)
+    a.srli(t1, src, 8)
+    a.li(t2, 0xFF00)
+    a.and_(t1, t1, t2)
+    a.or_(dst, dst, t1)
+    a.slli(t1, src, 8)
+    a.li(t2, 0xFF0000)
+    a.and_(t1, t1, t2)
+    a.or_(dst, dst, t1)
+
+
+def _write_pv(a, ptr_reg, nbytes):
+    """Commit the nbytes at ptr_reg as the guest's public values the way an SP1 guest does (sp1_zkvm::io::commit + the
+    runtime's exit path; reference crates/finalization_prove/src/main.rs:26-32): WRITE them to fd 3,
+    hash them with SHA-256 and COMMIT(k, word k) the eight digest words (little-endian words of the digest bytes)."""
+    assert nbytes % 4 == 0
+    uid = len(a.items)
+    buf = a.dword(f"pvbuf_{uid}", [0] * (nbytes // 4) + sha_padding(nbytes))
+    state = a.dword(f"pvstate_{uid}", SHA_H0)
+    emit_sha256(a)
     a.mv("s8", ptr_reg)
-    a.li("s9", nbytes // 4)
-    a.label(lab)
-    a.lw("a0", "s8", 0)
-    a.li("t0", SYS_COMMIT)
+    a.li("s9", buf)
+    a.li("s10", buf + nbytes)
+    if nbytes:
+        a.label(f"pvcopy_{uid}")
+        a.lw("t1", "s8", 0)
+        a.sw("t1", "s9", 0)
+        a.addi("s8", "s8", 4)
+        a.addi("s9", "s9", 4)
+        a.bne("s9", "s10", f"pvcopy_{uid}")
+    a.li("a0", 3)
+    a.li("a1", buf)
+    a.li("a2", nbytes)
+    a.li("t0", SYS_WRITE)
     a.ecall()
+    a.li("a0", buf)
+    a.li("a1", (nbytes + 4 * len(sha_padding(nbytes))) // 64)
+    a.li("a2", state)
+    a.call("sha256_blocks")
+    a.li("s8", state)
+    for k in range(8):
+        a.lw("t1", "s8", 4 * k)
+        _bswap(a, "a1", "t1", "t2", "t6")
+        a.li("a0", k)
+        a.li("t0", SYS_COMMIT)
+        a.ecall()
+
+
+def checksum(results: bytes) -> bytes:
+    """public values of the result-heavy test guests: the 32-bit sum of their result words (the results themselves go to
+    fd 1, so that the SHA-256 epilogue stays one block long)"""
+    return struct.pack("<I", sum(w for (w,) in struct.iter_unpack("<I", results)) & M32)
+
+
+def _finish(a, base, nbytes):
+    """WRITE the nbytes of results at `base` to fd 1, commit their word sum as the public values, HALT(0)"""
+    assert nbytes % 4 == 0 and nbytes
+    uid = len(a.items)
+    acc = a.dword(f"sum_{uid}", [0, 0])
+    a.li("a0", 1)
+    a.li("a1", base)
+    a.li("a2", nbytes)
+    a.li("t0", SYS_WRITE)
+    a.ecall()
+    a.li("s8", base)
+    a.li("s9", base + nbytes)
+    a.li("a5", 0)
+    a.label(f"sum_{uid}")
+    a.lw("a4", "s8", 0)
+    a.add("a5", "a5", "a4")
     a.addi("s8", "s8", 4)
-    a.addi("s9", "s9", -1)
-    a.bne("s9", "zero", lab)
+    a.bne("s8", "s9", f"sum_{uid}")
+    a.li("s1", acc)
+    a.sw("a5", "s1", 0)
+    _write_pv(a, "s1", 4)
+    a.halt(0)
 
 
-def arith():
-    """Every provable instruction on a few operand pairs; results go to public values."""
+def arith(commit=True):
+    """Every provable instruction on a few operand pairs.  Returns (elf, expected result bytes): the results go to fd 1 and
+    their checksum() to the public values (commit=False: they stay in memory and the guest halts without the SHA-256 /
+    COMMIT epilogue — a short trace for the per-cell soundness tests)."""
     pairs = [(0, 0), (1, M32), (0x80000000, 1), (0x7FFFFFFF, 0x80000000), (0x12345678, 0x9ABCDEF0), (M32, M32), (5, 3), (3, 5)]
     a = Asm()
-    out = a.dword("out", [0] * (len(pairs) * 16))
+    out = a.dword("out", [0] * (len(pairs) * 16 + 4))
     a.li("s0", out)
     exp = []
     sx = lambda v: v - (1 << 32) if v >> 31 else v
@@ -74,10 +280,23 @@ def arith():
     a.label("after")
     a.sw("a5", "s0", 0)
     exp.append((exp[-1] + 1) & M32)
-    a.li("s1", out)
-    _write_pv(a, "s1", 4 * len(exp))
-    a.halt(0)
+    if commit:
+        _finish(a, out, 4 * len(exp))
+    else:
+        a.halt(0)
     return a.elf(), b"".join(struct.pack("<I", v) for v in exp)
+
+
+def commit_only(payload=b""):
+    """The SP1 exit path alone: WRITE `payload` (a multiple of 4 bytes, from the data segment) to fd 3, hash it, COMMIT the
+    eight digest words, HALT(0)."""
+    assert len(payload) % 4 == 0
+    a = Asm()
+    src = a.dword("payload", [w for (w,) in struct.iter_unpack("<I", payload)] + [0])
+    a.li("s1", src)
+    _write_pv(a, "s1", len(payload))
+    a.halt(0)
+    return a.elf()
 
 
 def _bignum_consts(limbs):
@@ -294,9 +513,7 @@ def muldiv():
             a.sw("a5", "s0", 0)
             a.addi("s0", "s0", 4)
             exp.append(ref(op, b, c))
-    a.li("s1", out)
-    _write_pv(a, "s1", 4 * len(exp))
-    a.halt(0)
+    _finish(a, out, 4 * len(exp))
     return a.elf(), b"".join(struct.pack("<I", v) for v in exp)
 
 
@@ -326,9 +543,7 @@ def shifts():
                     a.sw("a5", "s0", 0)
                     a.addi("s0", "s0", 4)
                     exp.append(want)
-    a.li("s1", out)
-    _write_pv(a, "s1", 4 * len(exp))
-    a.halt(0)
+    _finish(a, out, 4 * len(exp))
     return a.elf(), b"".join(struct.pack("<I", v) for v in exp)
 
 
@@ -379,7 +594,5 @@ def subword():
         a.sw("a5", "s0", 0)
         a.addi("s0", "s0", 4)
         exp.append(mem[wi])
-    a.li("s1", out)
-    _write_pv(a, "s1", 4 * len(exp))
-    a.halt(0)
+    _finish(a, out, 4 * len(exp))
     return a.elf(), b"".join(struct.pack("<I", v) for v in exp)

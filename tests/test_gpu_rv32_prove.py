@@ -35,14 +35,14 @@ def test_arith_guest_proof_verifies(gpu):
     proof, rep = gpu.prove_core(pk)
     ok, ec, pv, why = capi.verify(vk, proof, Q, POW)
     assert ok, why
-    assert ec == 0 and pv == want and rep["exit_code"] == 0
+    assert ec == 0 and pv == guests.checksum(want) and rep["exit_code"] == 0
     # same input -> same proof bytes
     assert gpu.prove_core(pk)[0] == proof
-    # tampering anywhere is rejected: container header, the public-value bytes (bound through the
-    # COMMIT bus whose receiving side the verifier supplies), and the shard proofs
+    # tampering anywhere is rejected: container header, the public-value bytes (bound through the COMMITted
+    # words of their SHA-256 digest, whose receiving side the verifier supplies), and the shard proofs
     words = np.frombuffer(proof, dtype=np.uint32).copy()
     rng = np.random.default_rng(3)
-    body = 4 + (len(want) + 3) // 4
+    body = 4 + (len(pv) + 3) // 4
     for pos in [1, 2, 3, 4, 5, body - 1, body, body + 1] + list(rng.integers(4, len(words), 20)):
         w = words.copy()
         w[pos] = (int(w[pos]) + 1) % 2013265921
@@ -82,7 +82,7 @@ def test_subword_and_shift_guest_proofs(gpu, which):
     pk, vk = gpu.setup(elf)
     proof, rep = gpu.prove_core(pk)
     ok, ec, pv, why = capi.verify(vk, proof, Q, POW)
-    assert ok and pv == want, why
+    assert ok and pv == guests.checksum(want), why
     gpu.pk_free(pk)
 
 
@@ -91,7 +91,7 @@ def test_multi_shard_proof(gpu):
     challenges, memory bus balanced across shards, pc / shard-index chaining)"""
     from dvt_circuits_amd import capi
 
-    elf, want = guests.bignum(3, limbs=12)          # ~7k cycles -> 7 shards
+    elf, want = guests.bignum(3, limbs=12)          # ~7k cycles of arithmetic + ~11k of the SHA-256 exit path -> 18 shards
     p = capi.Prover(cfg(10))
     pk, vk = p.setup(elf)
     proof, rep = p.prove_core(pk)
@@ -133,7 +133,7 @@ def test_full_size_shard_on_the_reference_input():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, "tests", "golden", "finalization_example.json"), "rb") as f:
         buf = capi.stdin_from_json("finalization", f.read())
-    elf, want = guests.finalization_like(904, buf)
+    elf, want = guests.finalization_like(899, buf)
     p = capi.Prover("{}")
     pk, vk = p.setup(elf)
     proof, rep = p.prove_core(pk, [buf])
@@ -152,7 +152,7 @@ def test_full_size_shard_on_the_reference_input():
     other[100] ^= 1
     proof2, _ = p.prove_core(pk, [bytes(other)])
     ok2, _, pv2, _ = capi.verify(vk, proof2)
-    assert ok2 and pv2 != pv and pv2 == guests.finalization_like(904, bytes(other))[1]
+    assert ok2 and pv2 != pv and pv2 == guests.finalization_like(899, bytes(other))[1]
     p.pk_free(pk)
     p.close()
 
@@ -176,6 +176,41 @@ def test_phase2_recompute_path_gives_the_same_bytes(gpu):
     assert ok and pv == want, why
     p.pk_free(pk)
     p.close()
+
+
+def test_guest_without_the_commit_epilogue_is_refused(gpu):
+    """a guest that halts without COMMITting the SHA-256 digest of its public values could only yield a proof the
+    verifier rejects (the verifier supplies the receiving side of the public-values bus): prove refuses it up front"""
+    from dvt_circuits_amd import capi
+
+    pk, _ = gpu.setup(guests.arith(commit=False)[0])
+    with pytest.raises(capi.DvtError) as e:
+        gpu.prove_core(pk)
+    assert e.value.code == capi.DVT_ERR_GUEST and "COMMIT" in str(e.value)
+    gpu.pk_free(pk)
+
+
+def test_verify_rejects_hostile_containers(gpu):
+    """a crafted chip id used to index a stack array before any range check; parameter floors"""
+    from dvt_circuits_amd import capi
+
+    elf = guests.commit_only(b"abcd")
+    pk, vk = gpu.setup(elf)
+    proof, _ = gpu.prove_core(pk)
+    assert capi.verify(vk, proof, Q, POW)[0]
+    w = np.frombuffer(proof, np.uint32).copy()
+    # word layout: magic, n, exit code, pv length, pv words, shard length, then the shard proof: magic, 3 roots (24), pubs (1 + 5),
+    # chip count, first chip id
+    at = 4 + 1 + 1 + 1 + 24 + 6 + 1
+    assert w[at] == 0 and w[at - 1] in (5, 6)         # program chip first; 5 or 6 chips present
+    for evil in (0xFFFFFFFF, 64, 7):
+        t = w.copy()
+        t[at] = evil
+        assert not capi.verify(vk, t.tobytes(), Q, POW)[0]
+    for q, pw in ((0, POW), (Q, 31), (Q, 40), (5000, POW)):
+        ok, _, _, why = capi.verify(vk, proof, q, pw)
+        assert not ok
+    gpu.pk_free(pk)
 
 
 def test_error_classes(gpu):

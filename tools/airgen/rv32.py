@@ -35,6 +35,7 @@ BUSES = {"program": 1, "byte": 2, "mem": 3, "image": 4, "pv": 5, "alu": 6}
 ALU_SLL, ALU_SRL, ALU_SRA = 1, 2, 3
 ALU_MULH, ALU_MULHSU, ALU_DIV, ALU_DIVU, ALU_REM, ALU_REMU = 4, 5, 6, 7, 8, 9
 SYS_COMMIT = 0x10
+REG_A1 = 11
 
 # byte-table opcodes
 B_AND, B_OR, B_XOR, B_LTU, B_MSB, B_RANGE, B_U16 = 1, 2, 3, 4, 5, 6, 7
@@ -51,9 +52,13 @@ FLAGS = [
 # (aux = branch / jump target for the control-flow families, alu-bus opcode for is_alu rows: never both)
 N_INSTR_FIELDS = 1 + 3 + 4 + 4 + 1 + len(FLAGS)
 
-PUB_START_PC, PUB_NEXT_PC, PUB_EXIT_CODE, PUB_SHARD, PUB_IS_LAST, PUB_PV_START, PUB_PV_END = 0, 1, 2, 3, 4, 5, 6
-N_PUB = 7
+PUB_START_PC, PUB_NEXT_PC, PUB_EXIT_CODE, PUB_SHARD, PUB_IS_LAST = 0, 1, 2, 3, 4
+N_PUB = 5
 UNION_W = 26
+# every guest address (and every jump target) is below ADDR_TOP_BYTE << 24.  0x38000000 rather than 2^30 so that the sum
+# of an address and an address gap (both below it) stays below p = 2^31 - 2^27 + 1: the mem_init table's "strictly
+# increasing" check then holds over the integers, not only mod p.
+ADDR_TOP_BYTE = 0x38
 
 
 def build_program():
@@ -111,7 +116,7 @@ def build_cpu():
     pa_prev = ch.cols("pa_prev", 4)
     pa_ts, pa_lo, pa_hi = ch.col("pa_ts"), ch.col("pa_lo"), ch.col("pa_hi")
     U = ch.cols("u", UNION_W)
-    pv_idx, commit_m = ch.col("pv_idx"), ch.col("commit_m")
+    commit_m = ch.col("commit_m")
 
     # ---------------- row bookkeeping
     ch.assert_bool(is_real)
@@ -123,7 +128,10 @@ def build_cpu():
     ch.assert_zero(is_real_next * (pc.next() - next_pc), "trans")
     ch.assert_zero((is_real - is_real_next) * (next_pc - ch.pub(PUB_NEXT_PC)), "trans")
     ch.assert_zero(is_real * (next_pc - ch.pub(PUB_NEXT_PC)), "last")
-    for f in ("rd_en", "imm_c"):                                        # padding rows do nothing
+    # padding rows do nothing: EVERY flag column is zero there, not only their sum (two cancelling flags, e.g.
+    # is_ecall = 1 with is_lui = -1, would leave is_real = 0 while the family's interactions still fire);
+    # on real rows the program-table lookup pins all of them
+    for f in ["rd_en", "imm_c"] + FAMILY:
         ch.assert_zero((1 - is_real) * F[f])
 
     # ---------------- fetch
@@ -246,7 +254,7 @@ def build_cpu():
         ch.assert_zero(sel_adder * (acy[i] * (acy[i] - 1)))
     ch.send("byte", [B_RANGE, 0, s[0], s[1]], sel_adder + sel_mul)      # (MUL / MULHU: the bytes of x)
     ch.send("byte", [B_RANGE, 0, s[2], s[3]], sel_adder + sel_mul)
-    ch.send("byte", [B_LTU, 1, s[3], 0x40], sel_adder)        # address / target < 2^30
+    ch.send("byte", [B_LTU, 1, s[3], ADDR_TOP_BYTE], sel_adder)        # address / target < 0x38000000
     # JALR: u[8] = low bit cleared from the target
     jl = U[8]
     ch.assert_zero(F["is_jalr"] * (jl * (jl - 1)))
@@ -267,12 +275,14 @@ def build_cpu():
     ch.assert_zero((F["is_lw"] + F["is_sw"]) * (o1 + o2 + o3))                      # word access: aligned
     ch.assert_zero((F["is_lh"] + F["is_lhu"] + F["is_sh"]) * (o1 + o3))              # halfword access: even
     maddr = word(s) - o_val
-    ch.receive("mem", [maddr] + mp + [m_sh, m_ts], sel_mem)
-    ch.send("mem", [maddr] + mv + [shard, clk + 2], sel_mem)
-    ch.assert_zero(sel_mem * (m_same * (m_same - 1)))
-    ch.assert_zero(sel_mem * (m_same * (shard - m_sh)))
-    ch.assert_zero(sel_mem * (m_same * (clk + 2 - m_ts - 1) + (1 - m_same) * (shard - m_sh - 1) - m_lo - 65536 * m_hi))
-    ch.send("byte", [B_U16, 0, m_lo, 0], sel_mem + sel_mul)             # (MUL / MULHU: carry 4, also in u[8])
+    # (COMMIT ecalls read their second argument, register a1, through this port: commit_m rows pin the address to 11)
+    sel_port = sel_mem + commit_m
+    ch.receive("mem", [maddr] + mp + [m_sh, m_ts], sel_port)
+    ch.send("mem", [maddr] + mv + [shard, clk + 2], sel_port)
+    ch.assert_zero(sel_port * (m_same * (m_same - 1)))
+    ch.assert_zero(sel_port * (m_same * (shard - m_sh)))
+    ch.assert_zero(sel_port * (m_same * (clk + 2 - m_ts - 1) + (1 - m_same) * (shard - m_sh - 1) - m_lo - 65536 * m_hi))
+    ch.send("byte", [B_U16, 0, m_lo, 0], sel_port + sel_mul)            # (MUL / MULHU: carry 4, also in u[8])
     sel_load = F["is_lw"] + sel_loadsub
     for i in range(4):
         ch.assert_zero(F["is_lw"] * (a[i] - mv[i]))
@@ -308,25 +318,31 @@ def build_cpu():
     ch.assert_zero(sel_seq * (next_pc - pc - 4))
 
     # ECALL: b = t0 (syscall id), c = a0; a = new t0 (advice).  id 0 = HALT(exit code a0).
-    is_halt, id_inv = U[0], U[1]
+    # (witness cells in u[4..7]: u[0..3] hold the address bytes of the a1 read of COMMIT rows)
+    is_halt, id_inv = U[4], U[5]
     ec = F["is_ecall"]
     ch.assert_zero(ec * (is_halt * (is_halt - 1)))
     ch.assert_zero(ec * (is_halt * word(b)))
     ch.assert_zero(ec * (word(b) * id_inv - (1 - is_halt)))
     ch.assert_zero(ec * (next_pc - (1 - is_halt) * (pc + 4)))
     ch.assert_zero(ec * (is_halt * (word(c) - ch.pub(PUB_EXIT_CODE))))
-    # COMMIT (id 0x10, a0 = word): the k-th committed word of the execution is a public value.  The row
-    # sends (k, bytes of a0) on the "pv" bus; the VERIFIER supplies the receiving side from the claimed
-    # public values, so they are bound to the proof.  pv_idx counts the words committed before this row.
-    is_commit, cm_inv = U[2], U[3]
+    # COMMIT (id 0x10, a0 = index, a1 = word) — SP1's syscall contract: the guest hashes the bytes
+    # it wrote to fd 3 with SHA-256 and commits the eight digest words, COMMIT(k, digest word k), before HALT
+    # (reference crates/finalization_prove/src/main.rs:26-32 via sp1_zkvm::io::commit).  The row reads a1 = x11 through
+    # the memory port (address bytes u[0..3] = 11, no byte offset, value unchanged) and sends (index, bytes of the word)
+    # on the "pv" bus; the VERIFIER supplies the receiving side from SHA-256 of the claimed public-value bytes, so they
+    # are bound to the proof.
+    is_commit, cm_inv = U[6], U[7]
     ch.assert_zero(ec * (is_commit * (is_commit - 1)))
     ch.assert_zero(ec * (is_commit * (word(b) - SYS_COMMIT)))
     ch.assert_zero(ec * ((word(b) - SYS_COMMIT) * cm_inv - (1 - is_commit)))
     ch.assert_zero(commit_m - ec * is_commit)
-    ch.assert_eq(pv_idx, ch.pub(PUB_PV_START), "first")
-    ch.assert_zero(pv_idx.next() - pv_idx - commit_m, "trans")
-    ch.assert_zero(pv_idx + commit_m - ch.pub(PUB_PV_END), "last")
-    ch.send("pv", [pv_idx] + c, commit_m)
+    ch.assert_zero(commit_m * (s[0] - REG_A1))
+    for x in (s[1], s[2], s[3], o1, o2, o3):
+        ch.assert_zero(commit_m * x)
+    for i in range(4):
+        ch.assert_zero(commit_m * (mv[i] - mp[i]))
+    ch.send("pv", [word(c)] + mv, commit_m)
     return ch
 
 
@@ -507,18 +523,27 @@ def build_mem_image():
 
 def build_mem_init():
     ch = Chip("mem_init")
-    addr, v, f, fts, fsh = ch.col("addr"), ch.cols("v", 4), ch.cols("f", 4), ch.col("fts"), ch.col("fsh")
+    ab, v, f, fts, fsh = ch.cols("ab", 4), ch.cols("v", 4), ch.cols("f", 4), ch.col("fts"), ch.col("fsh")
     d = ch.cols("d", 4)
     is_img, is_real = ch.col("is_img"), ch.col("is_real")
+    addr = word(ab)
+    addr_next = word([x.next() for x in ab])
     ch.assert_bool(is_real)
     ch.assert_bool(is_img)
     ch.assert_zero(is_img * (1 - is_real))
     ch.assert_zero(is_real.next() * (1 - is_real), "trans")
-    # strictly increasing addresses: addr - prev.addr - 1 = d (4 bytes, < 2^30)
-    ch.assert_zero(is_real.next() * (addr.next() - addr - 1 - word([x.next() for x in d])), "trans")
+    # strictly increasing addresses OVER THE INTEGERS: the address itself is four range-checked bytes below 0x38000000,
+    # so is the gap d = addr' - addr - 1, hence addr + 1 + d < 2 * 0x38000000 < p cannot wrap (one initial tuple per address)
+    ch.assert_zero(is_real.next() * (addr_next - addr - 1 - word([x.next() for x in d])), "trans")
+    ch.send("byte", [B_RANGE, 0, ab[0], ab[1]], is_real)
+    ch.send("byte", [B_RANGE, 0, ab[2], ab[3]], is_real)
+    ch.send("byte", [B_LTU, 1, ab[3], ADDR_TOP_BYTE], is_real)
     ch.send("byte", [B_RANGE, 0, d[0], d[1]], is_real)
     ch.send("byte", [B_RANGE, 0, d[2], d[3]], is_real)
-    ch.send("byte", [B_LTU, 1, d[3], 0x40], is_real)
+    ch.send("byte", [B_LTU, 1, d[3], ADDR_TOP_BYTE], is_real)
+    # words outside the program image start with a prover-chosen value: that is how HINT_READ delivers the (private)
+    # stdin buffers, as in SP1, whose executor files hinted words as "uninitialized memory" values [EXTERNAL]; .bss is
+    # part of the image (zero words), stack and heap are written before they are read
     ch.send("byte", [B_RANGE, 0, v[0], v[1]], is_real - is_img)
     ch.send("byte", [B_RANGE, 0, v[2], v[3]], is_real - is_img)
     ch.send("image", [addr] + v, is_img)
