@@ -1,31 +1,36 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path named by BASELINE.json: prover guest-cycles/second
-(and proofs/hour) on MI355X.
+(and proofs/hour) on MI355X, measured over the WHOLE boundary call.
 
-A "step" = one proof of one execution of the finalization-shaped guest
-(tests/guests.py:finalization_like) on the reference's examples/finalization_test.json
-(kept as tests/golden/finalization_example.json), encoded exactly as the reference's
-host encodes it (typed JSON -> CBOR -> one SP1Stdin buffer, src/main.rs:451-460):
-K0 trace expansion .. K9 FRI queries over all its shards of 2^21 RV32IM cycles,
-with the compact execution records already resident in HBM.
-The execution has shards_per_gpu x N shards (weak scaling: N = 1 is the single-shard
-configuration BASELINE.json quotes); shard i is proven on GPU i mod N.  The only
-exchange is an all-gather of the 60-byte shard headers (main-trace root + public
-values) between phase 1 (main commitments) and phase 2 (everything else), from
-which every rank derives the common LogUp challenges.
-value = guest cycles of the execution x steps / max-over-ranks time.
+A "step" = one prove() of the reference's boundary (src/main.rs:449-478: execute the guest AND prove it):
+the DKG-shaped guest (tests/guests.py:dkg_like — finalization-shaped: read the one stdin buffer, per
+participant a SHA-256 commitment hash, signature-check and point-operation stand-ins (exact 384-bit
+multiply-accumulate chains), an n^2 term, SHA-256 + COMMIT of the public values) runs on the reference's
+examples/finalization_test.json (tests/golden/finalization_example.json), encoded exactly as the reference's
+host encodes it (typed JSON -> CBOR -> one SP1Stdin buffer), and its execution of
+shards_per_gpu x N shards of 2^21 RV32IM cycles is proven: host executor pipeline (one sequential fast pass
+cutting shards + traced re-execution of the owned shards on host threads), upload of the 48-byte cycle records,
+K0 trace expansion .. K9 FRI queries.  Nothing is resident in HBM when the timed region starts except the
+proving key (client.setup, src/main.rs:462, is per program, not per proof).
+
+N > 1 (torch.distributed.run, one process per GPU): shard i of the ONE execution is proven on GPU i mod N; every
+rank runs the sequential fast pass (it is the Amdahl term, counted inside the timed region) and traces only its own
+shards.  The only exchange is the all-gather of the 52-byte shard headers (main-trace root + public values)
+between phase 1 and phase 2 (RCCL over xGMI), from which every rank derives the common LogUp challenges.
+value = guest cycles of the execution x steps / max-over-ranks wall time.   scaling = "weak".
+
+--batch B: B independent single-shard proofs (the example input with distinct gen_id each), round-robin over the
+ranks, no collective on the data path (BASELINE configs[4], "replicas only").
 
 Extra objects on the JSON line (rank 0 prints exactly one line):
-  roofline      the dominant HBM-bound kernel family, K1 coset LDE: algorithmic bytes
-                (12 B per trace element: read N, write 2N words per column) divided by
-                the summed duration of its launches inside one prove, measured with HIP
-                events on the prover's own stream; "alu_bound_exception" carries the
-                Poseidon2 commitment kernels (K2/K3), which are integer-ALU bound
-  cpu_baseline  the oracle's CPU prover (tests/_oracle_prover.py over oracle/*.c,
-                OpenMP) timed on this box's host cores on two small shards; value =
-                marginal cycles/s between them (fixed table costs cancel)
+  roofline      the dominant HBM-classified kernel family, K1 coset LDE: algorithmic bytes (12 B per trace element:
+                read N, write 2N words per column) / summed duration of its launches inside one prove, HIP events on
+                the prover's own stream; "alu_bound_exception" carries the Poseidon2 commitment kernels (K2/K3)
+  cpu_baseline  the oracle's CPU prover (tests/_oracle_prover.py over oracle/*.c, OpenMP) on two bounded samples of the
+                same guest (smaller iteration constants), production parameters; value = marginal cycles/s
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -35,88 +40,102 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+LOG_SHARD = 21
 
 
-def workload_stdin(participants=0):
+def example_json():
+    with open(os.path.join(ROOT, "tests", "golden", "finalization_example.json"), "rb") as f:
+        return json.load(f)
+
+
+def workload_stdin(participants=0, instance=None):
     """the reference's own example input (or, with --participants N, a synthetic N-participant one in the same format:
-    tools/gen_dkg_input.py) through the reference's host-side encoding"""
+    tools/gen_dkg_input.py) through the reference's host-side encoding.  instance = i: the example with
+    gen_id = sha256("batch" || i)[:16] (distinct independent instances)."""
     from dvt_circuits_amd import capi
 
     if participants:
         from tools import gen_dkg_input
 
-        return capi.stdin_from_json("finalization", json.dumps(gen_dkg_input.finalization(participants, 2)).encode())
-    with open(os.path.join(ROOT, "tests", "golden", "finalization_example.json"), "rb") as f:
-        return capi.stdin_from_json("finalization", f.read())
+        doc = gen_dkg_input.finalization(participants, 2)
+    else:
+        doc = example_json()
+    if instance is not None:
+        doc["settings"]["gen_id"] = hashlib.sha256(b"batch" + str(instance).encode()).digest()[:16].hex()
+    return capi.stdin_from_json("finalization", json.dumps(doc).encode())
 
 
-def fit_iters(stdin_buf, total_shards, iters=0):
-    """largest multiply-accumulate count whose execution still fits total_shards shards of 2^21 cycles"""
+def fit_constants(stdin_buf, total_shards, sig=0):
+    """iteration constants (sig, pt, pair) of the guest so that the execution fills total_shards shards of 2^21 cycles
+    as closely as possible from below (pt = sig / 4: the reference's per-key work is a fraction of its pairing work)"""
     from dvt_circuits_amd import capi
     from tests import guests
 
-    if iters:
-        return iters
-    iters = 907 * total_shards
+    def cycles(s):
+        c = (s, max(1, s // 4), 1)
+        return capi.execute(guests.dkg_like("finalization", *c), [stdin_buf])[1]["cycles"], c
+
+    if sig:
+        return cycles(sig)[1]
+    target = total_shards << LOG_SHARD
+    c1, c2 = cycles(4)[0], cycles(8)[0]
+    per = (c2 - c1) / 4.0
+    s = max(1, int((target - c1) / per) + 4)
     while True:
-        cycles = capi.execute(guests.finalization_like(iters, stdin_buf)[0], [stdin_buf])[1]["cycles"]
-        over = cycles - (total_shards << 21)
-        if over <= 0:
-            return iters
-        iters -= over // 2300 + 1
+        c, consts = cycles(s)
+        if c <= target:
+            return consts
+        s -= max(1, int((c - target) / per))
 
 
-def cpu_baseline(small_iters, big_iters):
+def cpu_baseline(stdin_buf, sizes):
     """Oracle CPU prover on two bounded samples of the same workload (rank 0, N = 1 only)."""
     from dvt_circuits_amd import capi
-    from tests import _oracle_prover, guests
+    from tests import _oracle_prover, _orc, guests
 
-    buf = workload_stdin()
     pts = []
-    for it in (small_iters, big_iters):
-        elf, _ = guests.finalization_like(it, buf)
-        chips, pubs, _ = capi.rv32_debug_traces(elf, [buf])
-        cyc = capi.execute(elf, [buf])[1]["cycles"]
+    for s in sizes:
+        elf = guests.dkg_like("finalization", s, max(1, s // 4), 1)
+        chips, pubs, _ = capi.rv32_debug_traces(elf, [stdin_buf])
+        cyc = capi.execute(elf, [stdin_buf])[1]["cycles"]
         t = time.perf_counter()
         gc = _oracle_prover.global_challenges(_oracle_prover.prep_root_of(chips), [_oracle_prover.main_root(chips) + [int(x) for x in pubs]])
-        _oracle_prover.prove_shard("rv32", chips, pubs, 100, 4, perm_challenges=gc)
+        _oracle_prover.prove_shard("rv32", chips, pubs, 100, 16, perm_challenges=gc)
         pts.append((cyc, time.perf_counter() - t))
     (c0, t0), (c1, t1) = pts
-    from tests import _orc
-
     cores = int(_orc.load().lib.orc_num_threads())  # OpenMP threads the oracle actually ran with
-    marginal = (c1 - c0) / max(t1 - t0, 1e-9)
     return {
-        "value": marginal,
+        "value": (c1 - c0) / max(t1 - t0, 1e-9),
         "unit": "guest cycles/s",
         "cores": cores,
         "kind": "port",
-        "sample": "in-repo CPU restatement (oracle, C + OpenMP, not SP1): same guest at %d cycles (%.1f s) and %d cycles (%.1f s), "
-                  "100 FRI queries, 4 PoW bits; value = marginal rate between the two (the 2^16-row byte table is a fixed cost); "
-                  "whole-sample rate of the larger one = %.0f cycles/s" % (c0, t0, c1, t1, c1 / t1),
+        "parity": "unpinned against stock SP1 (the reference's prover cannot be built here); the GPU proof bytes are checked against this port",
+        "sample": "in-repo CPU restatement (oracle, C + OpenMP, Python-orchestrated; not SP1): the bench guest at %d cycles (%.1f s) and %d "
+                  "cycles (%.1f s), 100 FRI queries, 16 PoW bits; value = marginal rate between the two (the 2^16-row byte table is a "
+                  "fixed cost); whole-sample rate of the larger one = %.0f cycles/s" % (c0, t0, c1, t1, c1 / t1),
     }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--iters", type=int, default=0, help="multiply-accumulate iterations of the guest (default 907 per shard - 3: ~2.096M cycles fill one 2^21-cycle shard)")
-    ap.add_argument("--shards-per-gpu", type=int, default=1, help="weak scaling: the execution has shards_per_gpu x n_gpus shards")
-    ap.add_argument("--cpu-small", type=int, default=112)
-    ap.add_argument("--cpu-big", type=int, default=224)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--shards-per-gpu", type=int, default=32, help="weak scaling: the execution has shards_per_gpu x n_gpus shards of 2^21 cycles")
+    ap.add_argument("--sig-iters", type=int, default=0, help="guest iteration constant (0 = fitted to the shard count)")
+    ap.add_argument("--participants", type=int, default=0, help="0 = the reference's finalization example (n = 3); N = synthetic N-participant "
+                    "input of the same format (tools/gen_dkg_input.py), e.g. 255")
+    ap.add_argument("--batch", type=int, default=0, help="B independent single-shard proofs round-robin over the ranks instead of one sharded execution")
+    ap.add_argument("--exec-threads", type=int, default=0)
+    ap.add_argument("--cpu-sizes", type=int, nargs=2, default=[20, 60])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--participants", type=int, default=0, help="0 = the reference's finalization example (BASELINE configs[1]); N = synthetic "
-                    "N-participant input of the same format (tools/gen_dkg_input.py), e.g. 255")
     args = ap.parse_args()
 
     import torch
 
     from dvt_circuits_amd import capi
+    from dvt_circuits_amd.dist_util import Ranks
     from tests import guests
-
-    from dvt_circuits_amd.dist_util import Ranks, whole_job_rate
 
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
@@ -136,84 +155,116 @@ def main():
         ranks.barrier()
         torch.cuda.synchronize()
 
-    # workload: one execution of (shards_per_gpu x world) shards of 2^21 cycles; rank r owns shards r, r+world, ...
-    total_shards = args.shards_per_gpu * world
+    cfg = '{"device": %d, "fri_queries": 100, "pow_bits": 16, "log_shard_size": %d, "exec_threads": %d}' % (local, LOG_SHARD, args.exec_threads)
+    prover = capi.Prover(cfg)
     stdin_buf = workload_stdin(args.participants)
-    iters = fit_iters(stdin_buf, total_shards, args.iters)
-    elf, want_pv = guests.finalization_like(iters, stdin_buf)
-    prover = capi.Prover('{"device": %d, "fri_queries": 100, "pow_bits": 16, "log_shard_size": 21}' % local)
-    pk, vk = prover.setup(elf)
-    t_host = time.perf_counter()
-    job, rep = prover.prepare(pk, [stdin_buf])
-    t_host = time.perf_counter() - t_host
-    cycles = int(rep["cycles"])
-    n_shards = prover.job_shards(job)
-    mine = ranks.shard_of(n_shards)
+    extra = {}
 
-    def exchange_headers(local_headers):
-        """the one exchange step of the path: all-gather of the 15-word shard headers (RCCL over xGMI)"""
-        import numpy as np
+    if args.batch:
+        # ---------------------------------------------------------------- B independent proofs ("replicas only")
+        consts = fit_constants(stdin_buf, 1, args.sig_iters)
+        elf = guests.dkg_like("finalization", *consts)
+        pk, vk = prover.setup(elf)
+        inputs = [workload_stdin(args.participants, instance=i) for i in range(args.batch)]
+        mine = ranks.shard_of(args.batch)
+        # correctness outside the timed region: this rank's first proof verifies with the public values the guest must commit
+        if mine:
+            proof, rep = prover.prove_core(pk, [inputs[mine[0]]])
+            ok, ec, pv, why = capi.verify(vk, proof, 100, 16)
+            assert ok and ec == 0 and pv == guests.dkg_like_expected(inputs[mine[0]], "finalization", *consts), f"bench proof rejected: {why}"
+        cyc_mine = 0
 
-        if world == 1:
-            return np.stack(local_headers)
-        h = torch.zeros((n_shards, 15), dtype=torch.int64, device=coll)
-        for i, hd in zip(mine, local_headers):
-            h[i] = torch.from_numpy(hd.astype(np.int64)).to(coll)
-        ranks.dist.all_reduce(h)   # disjoint rows: sum == gather
-        return h.cpu().numpy().astype(np.uint32)
+        def step():
+            nonlocal cyc_mine
+            cyc_mine = 0
+            for i in mine:
+                _, rep = prover.prove_core(pk, [inputs[i]])
+                cyc_mine += int(rep["cycles"])
 
-    def prove_once(want_bytes):
-        headers = exchange_headers([prover.commit_shard(pk, job, i) for i in mine])
-        ch = capi.rv32_challenges(vk, headers)
-        return [prover.prove_shard(pk, job, i, ch, want_bytes=want_bytes) for i in mine]
-
-    # correctness outside the timed region: the proof this configuration produces must verify
-    shard_proofs = prove_once(True)
-    if world == 1:
-        proof = prover.assemble(job, shard_proofs)
-        ok, ec, pv, why = capi.verify(vk, proof, 100, 16)
-        assert ok and pv == want_pv and ec == 0, f"bench proof rejected: {why}"
-    else:
-        import numpy as np
-
-        lens = torch.zeros(n_shards, dtype=torch.int64, device=coll)
-        for i, sp in zip(mine, shard_proofs):
-            lens[i] = len(sp)
-        ranks.dist.all_reduce(lens)
-        mx = int(lens.max().item())
-        buf = torch.zeros((n_shards, mx), dtype=torch.uint8, device=coll)
-        for i, sp in zip(mine, shard_proofs):
-            buf[i, : len(sp)] = torch.frombuffer(bytearray(sp), dtype=torch.uint8).to(coll)
-        ranks.dist.all_reduce(buf)
-        if rank == 0:
-            allp = [bytes(buf[i, : int(lens[i].item())].cpu().numpy()) for i in range(n_shards)]
-            ok, ec, pv, why = capi.verify(vk, prover.assemble(job, allp), 100, 16)
-            assert ok and pv == want_pv and ec == 0, f"bench proof rejected: {why}"
-
-    for _ in range(args.warmup):
-        prove_once(False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        prove_once(False)
-    prover.sync()
-    barrier()
-    dt = ranks.max_over_ranks(time.perf_counter() - t0)
-
-    # end-to-end rate including host execution + PCIe upload (reported, never `value`)
-    e2e = None
-    if world == 1:
-        t1 = time.perf_counter()
-        j2, _ = prover.prepare(pk, [stdin_buf])
-        prover.prove_job(pk, j2, want_bytes=False)
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
         prover.sync()
-        e2e = time.perf_counter() - t1
-        prover.job_free(j2)
+        barrier()
+        dt = ranks.max_over_ranks(time.perf_counter() - t0)
+        t = torch.tensor([float(cyc_mine)], dtype=torch.float64, device=coll)
+        if ranks.dist:
+            ranks.dist.all_reduce(t)
+        cycles = int(t.item())
+        n_shards = args.batch
+        workload = ("BASELINE configs[4] shape: batch of %d independent single-shard proofs of the finalization-shaped guest, each on the "
+                    "reference's example input with its own gen_id, round-robin over %d rank(s), no collective" % (args.batch, world))
+        extra["proofs_per_hour"] = args.batch * args.steps * 3600.0 / dt
+        parallelism = "independent proofs, proof i on GPU i mod %d (replicas only)" % world
+    else:
+        # ---------------------------------------------------------------- one execution, shard-parallel
+        total_shards = args.shards_per_gpu * world
+        consts = fit_constants(stdin_buf, total_shards, args.sig_iters)
+        elf = guests.dkg_like("finalization", *consts)
+        pk, vk = prover.setup(elf)
+        want_pv = guests.dkg_like_expected(stdin_buf, "finalization", *consts)
+        state = {}
 
-    # kernel-family timing on a profiled handle (HIP events on the prover stream, same shard)
+        def prove_once(want_bytes):
+            job, rep = prover.prepare(pk, [stdin_buf], first=rank, stride=world)    # executor pipeline + upload + phase 1
+            n = prover.job_shards(job)
+            mine = ranks.shard_of(n)
+            headers = ranks.exchange_headers(n, [prover.commit_shard(pk, job, i) for i in mine])   # the one exchange step
+            ch = capi.rv32_challenges(vk, headers)
+            proofs = [prover.prove_shard(pk, job, i, ch, want_bytes=want_bytes) for i in mine]     # phase 2
+            state.update(cycles=int(rep["cycles"]), n_shards=n, exec_wait=prover.job_exec_wait(job))
+            if want_bytes:
+                allp = ranks.gather_proofs(n, proofs)
+                full = prover.assemble(job, allp)
+                prover.job_free(job)
+                return full
+            prover.job_free(job)
+            return None
+
+        # correctness outside the timed region: the proof this configuration produces must verify
+        full = prove_once(True)
+        if rank == 0:
+            ok, ec, pv, why = capi.verify(vk, full, 100, 16)
+            assert ok and pv == want_pv and ec == 0, f"bench proof rejected: {why}"
+        del full
+        for _ in range(args.warmup):
+            prove_once(False)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            prove_once(False)
+        prover.sync()
+        barrier()
+        dt = ranks.max_over_ranks(time.perf_counter() - t0)
+        cycles, n_shards = state["cycles"], state["n_shards"]
+        extra["executor_wait_seconds_per_step_rank0"] = state["exec_wait"]
+        extra["proofs_per_hour"] = args.steps * 3600.0 / dt
+        workload = (("synthetic %d-participant finalization input (tools/gen_dkg_input.py, reference format)" % args.participants if args.participants else
+                     "BASELINE configs[1] input: examples/finalization_test.json (tests/golden/finalization_example.json)") +
+                    " through the reference's JSON -> CBOR -> SP1Stdin encoding, executed AND proven (the whole prove() call) by the "
+                    "finalization-shaped synthetic guest tests/guests.py:dkg_like%r: %d shards of 2^21 RV32IM cycles; the reference's own guest ELF is "
+                    "prebuilt machine code and is not run (it would be 511 shards on this input, SURVEY.md App. B.3)" % (tuple(consts), n_shards))
+        parallelism = "one execution, shard i on GPU i mod %d; all-gather of 52-byte shard headers between the two phases" % world
+
+    # ---- secondary figures on one single-shard execution: resident prove rate, kernel-family timing (profile handle)
+    one = fit_constants(stdin_buf, 1)
+    elf1 = guests.dkg_like("finalization", *one)
+    pk1, _ = prover.setup(elf1)
+    job1, rep1 = prover.prepare(pk1, [stdin_buf])
+    prover.prove_job(pk1, job1, want_bytes=False)
+    prover.sync()
+    t1 = time.perf_counter()
+    for _ in range(3):
+        prover.prove_job(pk1, job1, want_bytes=False)
+    prover.sync()
+    resident = 3 * int(rep1["cycles"]) / (time.perf_counter() - t1)
+    prover.job_free(job1)
+    prover.pk_free(pk1)
     prof = capi.Prover('{"device": %d, "fri_queries": 100, "pow_bits": 16, "profile": 1}' % local)
-    pelf, _ = guests.finalization_like(fit_iters(stdin_buf, 1), stdin_buf)           # one shard
-    ppk, _ = prof.setup(pelf)
+    ppk, _ = prof.setup(elf1)
     pjob, _ = prof.prepare(ppk, [stdin_buf])
     prof.prove_job(ppk, pjob, want_bytes=False)
     prof.prove_job(ppk, pjob, want_bytes=False)
@@ -225,11 +276,14 @@ def main():
     lde_gbps = ks["lde_alg_bytes"] / (ks["lde_ms"] * 1e-3) / 1e9 if ks["lde_ms"] else 0.0
     # compulsory streams of the whole shard, each counted once
     shard_alg = 36 * ks["cells_main"] + 36 * ks["cells_perm"] + 28 * ks["cells_quotient"] + 24 * ks["cells_prep"]
-    step_s = dt / args.steps / max(len(mine), 1)
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1c_pmc_k1_traffic.json")))
-    except OSError:
-        pmc = {}
+    pmc = {}
+    for name in ("r2_pmc_k1_traffic.json", "r1c_pmc_k1_traffic.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            pmc["_file"] = name
+            break
+        except OSError:
+            pass
 
     out = {
         "metric": "SP1 prover cycles/sec + proofs/hour, finalization_prove at 1/2/4/8 MI355X",
@@ -244,26 +298,21 @@ def main():
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",
-        "config": {
-            "workload": ("synthetic %d-participant finalization input (tools/gen_dkg_input.py, reference format) through the reference's " % args.participants
-                         if args.participants else
-                         "BASELINE configs[1]: examples/finalization_test.json (tests/golden/finalization_example.json) through the reference's ") +
-                        "JSON -> CBOR -> SP1Stdin encoding, proven by the finalization-shaped synthetic guest (tests/guests.py:finalization_like: "
-                        "reads the buffer, 384-bit multiply-accumulate seeded by it), one shard of ~2^21 RV32IM cycles; the reference's own guest "
-                        "ELF is prebuilt machine code and is not run",
+        "config": dict({
+            "workload": workload,
+            "measured_unit": "the whole boundary call: host execution of the guest + record upload + K0..K9 (reference src/main.rs:461-466)",
             "stdin_bytes": len(stdin_buf),
             "participants": args.participants or 3,
-            "guest_cycles_per_proof": cycles,
-            "shards_per_proof": n_shards,
-            "shards_per_gpu": args.shards_per_gpu,
+            "guest_cycles_per_step": cycles,
+            "shards_per_step": n_shards,
+            "shards_per_gpu": args.shards_per_gpu if not args.batch else None,
             "fri_queries": 100,
             "pow_bits": 16,
             "log_blowup": 1,
-            "parallelism": "one execution, shard i on GPU i mod %d; all-gather of 60-byte shard headers between the two phases" % world,
-            "proofs_per_hour": args.steps * 3600.0 / dt,
-            "end_to_end_cycles_per_s_incl_host_exec_and_pcie": (cycles / e2e) if e2e else None,
-            "host_prepare_seconds": t_host,
-        },
+            "parallelism": parallelism,
+            "resident_single_shard_cycles_per_s": resident,
+            "resident_note": "K0..K9 of one ~2^21-cycle shard whose cycle records are already in HBM (round 1's headline figure), for comparison",
+        }, **extra),
         "roofline": {
             "bound": "hbm",
             "kernel": "K1 coset LDE (ntt_strided_kernel<true> + lde_block_kernel + ntt_strided_kernel<false>), %d calls per proof" % ks["lde_calls"],
@@ -272,8 +321,8 @@ def main():
             "unit": "GB/s",
             "frac": lde_gbps / HBM_PEAK_GBPS,
             "traffic": pmc.get("k1_hbm_bytes_per_proof"),
-            "traffic_source": "profiles/r1c_pmc_k1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this command, "
-                              "gfx950 FETCH_SIZE x2 correction applied where the guide prescribes it); bytes per proof, like alg_bytes_per_proof",
+            "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 FETCH_SIZE x2 correction applied "
+                              "where the guide prescribes it); bytes per single-shard proof, like alg_bytes_per_proof" % pmc.get("_file", "(none)"),
             "alg_bytes_per_proof": ks["lde_alg_bytes"],
             "ms_per_proof": ks["lde_ms"],
         },
@@ -287,15 +336,14 @@ def main():
             "alg_bytes": shard_alg,
             "formula": "36 M + 36 P + 28 Q + 24 Pre (field elements of the main / permutation / quotient / preprocessed traces)",
             "cells": {k: ks["cells_" + k] for k in ("main", "perm", "quotient", "prep")},
-            "achieved_GBps": shard_alg / step_s / 1e9,
-            "frac_of_hbm_peak": shard_alg / step_s / 1e9 / HBM_PEAK_GBPS,
+            "achieved_GBps_resident": shard_alg * resident / max(int(rep1["cycles"]), 1) / 1e9,
+            "frac_of_hbm_peak_resident": shard_alg * resident / max(int(rep1["cycles"]), 1) / 1e9 / HBM_PEAK_GBPS,
         },
     }
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_small, args.cpu_big)
+            out["cpu_baseline"] = cpu_baseline(stdin_buf, args.cpu_sizes)
         print(json.dumps(out), flush=True)
-    prover.job_free(job)
     prover.pk_free(pk)
     prover.close()
     ranks.close()

@@ -26,6 +26,31 @@ r.close()
 """
 
 
+EXCHANGE_WORKER = r"""
+import os, sys, struct
+import numpy as np
+sys.path.insert(0, %r)
+from dvt_circuits_amd import capi
+from dvt_circuits_amd.dist_util import Ranks, HEADER_WORDS
+r = Ranks(backend="gloo")
+n = 5
+rng = np.random.default_rng(7)
+all_headers = rng.integers(0, 2013265921, size=(n, HEADER_WORDS), dtype=np.uint32)     # what a single process would hold
+mine = r.shard_of(n)
+got = r.exchange_headers(n, [all_headers[i] for i in mine])                              # each rank contributes only its own
+assert got.shape == (n, HEADER_WORDS) and (got == all_headers).all(), "exchange_headers lost or reordered a header"
+vk = struct.pack("<I", 0x314b5644) + b"rv32".ljust(16, b"\0") + struct.pack("<8I", *range(1, 9)) + struct.pack("<I", 3) \
+     + struct.pack("<6I", 0, 6, 1, 16, 3, 7) + struct.pack("<2I", 1, 0x200800)
+ch = capi.rv32_challenges(vk, got)
+proofs = r.gather_proofs(n, [b"proof-%%d" %% i * (i + 1) for i in mine])
+assert proofs == [b"proof-%%d" %% i * (i + 1) for i in range(n)]
+print("CH", r.rank, " ".join(str(int(x)) for x in ch))
+if r.rank == 0:
+    print("SINGLE", " ".join(str(int(x)) for x in capi.rv32_challenges(vk, all_headers)))
+r.close()
+"""
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -44,6 +69,21 @@ def test_world_size_2_gloo_barrier_max_and_sharding():
     assert all(p.returncode == 0 for p in procs), outs
     assert "RESULT 2 True [0, 2, 4] 4000.0" in outs[0][0]
     assert "OTHER [1, 3]" in outs[1][0]
+
+
+def test_world_size_2_header_exchange_and_common_challenges():
+    """the one exchange step of the multi-GPU path on CPU (gloo, world size 2): every rank contributes the headers of its
+    own shards, gets all of them back in shard order, and derives from them the SAME LogUp challenges a single process
+    derives (dvt_rv32_challenges is host-only); the proof gather returns the shard proofs in shard order"""
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", EXCHANGE_WORKER % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=180) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    lines = {ln.split()[0] + ln.split()[1] if ln.startswith("CH") else "SINGLE": ln.split()[2 if ln.startswith("CH") else 1:] for o in outs for ln in o[0].splitlines() if ln.startswith(("CH", "SINGLE"))}
+    assert lines["CH0"] == lines["CH1"] == lines["SINGLE"] and len(lines["SINGLE"]) == 8
 
 
 def test_bench_line_fields_of_committed_profile():

@@ -64,17 +64,32 @@ def test_toy_proof_bytes_equal_oracle(shape):
     p.close()
 
 
-@pytest.mark.parametrize("log_shard,which", [(21, "bignum"), (8, "bignum"), (9, "shifts"), (10, "muldiv")])
+def _encshare_case():
+    """the bad_encrypted_share-shaped guest on a synthetic n = 3 input: SHA-256 KDF, ChaCha20, divu, the n^2 loop"""
+    import json
+
+    from dvt_circuits_amd import capi
+    from tools import gen_dkg_input
+
+    buf = capi.stdin_from_json("bad-encrypted-share", json.dumps(gen_dkg_input.bad_encrypted_share(3, 2)).encode())
+    return guests.dkg_like("encshare"), guests.dkg_like_expected(buf, "encshare"), [buf]
+
+
+@pytest.mark.parametrize("log_shard,which", [(21, "bignum"), (8, "bignum"), (9, "shifts"), (10, "muldiv"), (16, "encshare")])
 def test_rv32_proof_bytes_equal_oracle(log_shard, which):
     from dvt_circuits_amd import capi
 
-    elf, want = guests.bignum(2, limbs=3) if which == "bignum" else getattr(guests, which)()
+    stdin = ()
+    if which == "encshare":
+        elf, want, stdin = _encshare_case()
+    else:
+        elf, want = guests.bignum(2, limbs=3) if which == "bignum" else getattr(guests, which)()
     p = capi.Prover('{"fri_queries": %d, "pow_bits": %d, "log_shard_size": %d}' % (Q, POW, log_shard))
     pk, vk = p.setup(elf)
-    proof, rep = p.prove_core(pk)
+    proof, rep = p.prove_core(pk, stdin)
     ec, pv, gpu_shards = split_container(proof)
-    assert ec == 0 and pv == (want if which == "bignum" else guests.checksum(want))
-    cpu_shards = oracle_prove_execution(elf, (), log_shard)
+    assert ec == 0 and pv == (want if which in ("bignum", "encshare") else guests.checksum(want))
+    cpu_shards = oracle_prove_execution(elf, stdin, log_shard)
     assert len(gpu_shards) == len(cpu_shards) and (len(gpu_shards) > 1) == (log_shard < 21)
     for i, (g, c) in enumerate(zip(gpu_shards, cpu_shards)):
         assert g == c, f"shard {i}: first differing word / lengths: {first_diff(g, c)}"

@@ -1,0 +1,39 @@
+"""Byte parity at PRODUCTION size (collected last on purpose: it is the slowest test and must not hide the others
+behind `pytest -x`): one full shard of ~2^21 RV32IM cycles of the bench guest on the reference's example input, 100 FRI
+queries, 16 proof-of-work bits — the GPU prover's shard proof must equal the oracle CPU prover's, byte for byte.
+(at this size K4..K9 were only checked through properties.)"""
+import os
+
+import numpy as np
+import pytest
+
+from tests import _oracle_prover, guests
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_full_size_shard_bytes_equal_oracle():
+    import bench
+    from dvt_circuits_amd import capi
+
+    buf = bench.workload_stdin()
+    consts = bench.fit_constants(buf, 1)
+    elf = guests.dkg_like("finalization", *consts)
+    p = capi.Prover("{}")
+    pk, vk = p.setup(elf)
+    proof, rep = p.prove_core(pk, [buf])
+    assert (1 << 21) - 8192 < rep["cycles"] <= 1 << 21
+    ok, ec, pv, why = capi.verify(vk, proof)
+    assert ok and pv == guests.dkg_like_expected(buf, "finalization", *consts), why
+    w = np.frombuffer(proof, np.uint32)
+    assert int(w[1]) == 1
+    shard_gpu = w[4 + (len(pv) + 3) // 4 + 1:].tobytes()
+    chips, pubs, n_shards = capi.rv32_debug_traces(elf, [buf])
+    assert n_shards == 1 and max(c["main"].shape[1] for c in chips) == 1 << 21
+    gc = _oracle_prover.global_challenges(_oracle_prover.prep_root_of(chips), [_oracle_prover.main_root(chips) + [int(x) for x in pubs]])
+    shard_cpu, _ = _oracle_prover.prove_shard("rv32", chips, pubs, 100, 16, perm_challenges=gc)
+    wa, wb = np.frombuffer(shard_gpu, np.uint32), np.frombuffer(shard_cpu, np.uint32)
+    assert len(wa) == len(wb) and (wa == wb).all(), f"first differing word {int(np.nonzero(wa[:min(len(wa), len(wb))] != wb[:min(len(wa), len(wb))])[0][0]) if len(wa) == len(wb) else (len(wa), len(wb))}"
+    p.pk_free(pk)
+    p.close()

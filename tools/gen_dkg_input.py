@@ -53,11 +53,33 @@ def finalization(n, k, seed=None):
     return {"settings": {"n": n, "k": k, "gen_id": gen_id.hex()}, "generations": gens, "aggregate_pubkey": rnd.take(48).hex()}
 
 
+def bad_encrypted_share(n, k, seed=None):
+    """Synthetic `bad-encrypted-share` input (crates/dkg/src/types.rs:182-203): n base hashes, k + k base pubkeys, a
+    178-byte share message (crates/bad_encrypted_share_prove/src/main.rs:150-176: gen_id[16] || type = 3 || secret[32]
+    || commit_hash[32] || commit_pubkey[33] || commit_sig[64]) as the hex string `encrypted_data`.  Same caveat as
+    finalization(): field sizes and structure are the reference's, the key material is pseudo-random bytes."""
+    assert 1 <= k <= n <= 255
+    rnd = Stream(0xD17C0DE5 + 1000 + n if seed is None else seed)
+    gen_id = rnd.take(16)
+    message = gen_id + bytes([3]) + rnd.take(32) + rnd.take(32) + rnd.take(33) + rnd.take(64)
+    return {
+        "sender_pubkey": rnd.take(33).hex(),
+        "sender_encr_pubkey": rnd.take(48).hex(),
+        "receiver_encr_seckey": rnd.take(32).hex(),
+        "encrypted_data": message.hex(),
+        "settings": {"n": n, "k": k, "gen_id": gen_id.hex()},
+        "base_hashes": sorted(rnd.take(32).hex() for _ in range(n)),
+        "sender_base_pubkeys": [rnd.take(48).hex() for _ in range(k)],
+        "receiver_base_pubkeys": [rnd.take(48).hex() for _ in range(k)],
+    }
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, required=True)
     ap.add_argument("--k", type=int, default=2)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=None)
+    ap.add_argument("--type", choices=("finalization", "bad-encrypted-share"), default="finalization")
     a = ap.parse_args()
-    json.dump(finalization(a.n, a.k, a.seed), sys.stdout, indent=1)
+    json.dump((finalization if a.type == "finalization" else bad_encrypted_share)(a.n, a.k, a.seed), sys.stdout, indent=1)
     sys.stdout.write("\n")
