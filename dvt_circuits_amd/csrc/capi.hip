@@ -463,17 +463,18 @@ struct dvt_job {
     ShardJob *at(size_t pos) { return pos >= first && (pos - first) % stride == 0 && (pos - first) / stride < shards.size() ? &shards[(pos - first) / stride] : nullptr; }
 };
 
-static void job_release(dvt_job *j) {
+static void job_release(dvt_prover *p, dvt_job *j) {
     if (!j) return;
+    DevPool &pool = p->eng.pool;
     for (auto &s : j->shards) {
-        if (s.d_recs) (void)hipFree(s.d_recs);
-        for (auto &d : s.d_aux) if (d) (void)hipFree(d);
-        for (uint32_t *d : {s.d_cpu, s.d_byte, s.d_prog}) if (d) (void)hipFree(d);
+        pool.free(s.d_recs);
+        for (auto &d : s.d_aux) pool.free(d);
+        for (uint32_t *d : {s.d_cpu, s.d_byte, s.d_prog}) pool.free(d);
         s.cache.release();
     }
-    if (j->d_cpu) (void)hipFree(j->d_cpu);
-    if (j->d_byte) (void)hipFree(j->d_byte);
-    if (j->d_prog) (void)hipFree(j->d_prog);
+    pool.free(j->d_cpu);
+    pool.free(j->d_byte);
+    pool.free(j->d_prog);
     delete j;
 }
 
@@ -484,11 +485,11 @@ static int shard_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *j, ShardJob &s
     const MachineDesc *m = machine_rv32();
     if (!s.d_cpu && (!j->d_cpu || j->work_log_cpu < s.log_n[RV32_CHIP_CPU])) {   // working buffers, sized for the largest shard seen
         HIP_TRY(p, hipStreamSynchronize(st));
-        for (uint32_t **d : {&j->d_cpu, &j->d_byte, &j->d_prog}) { if (*d) (void)hipFree(*d); *d = nullptr; }
+        for (uint32_t **d : {&j->d_cpu, &j->d_byte, &j->d_prog}) { p->eng.pool.free(*d); *d = nullptr; }
         j->work_log_cpu = s.log_n[RV32_CHIP_CPU];
-        HIP_TRY(p, hipMalloc(&j->d_cpu, ((size_t)RV32_CPU_MAIN_W << j->work_log_cpu) * 4));
-        HIP_TRY(p, hipMalloc(&j->d_byte, j->byte_words * 4));
-        HIP_TRY(p, hipMalloc(&j->d_prog, j->prog_words * 4));
+        HIP_TRY(p, p->eng.pool.alloc(&j->d_cpu, ((size_t)RV32_CPU_MAIN_W << j->work_log_cpu) * 4));
+        HIP_TRY(p, p->eng.pool.alloc(&j->d_byte, j->byte_words * 4));
+        HIP_TRY(p, p->eng.pool.alloc(&j->d_prog, j->prog_words * 4));
     }
     uint32_t *cpu = s.d_cpu ? s.d_cpu : j->d_cpu, *byte = s.d_cpu ? s.d_byte : j->d_byte, *prog = s.d_cpu ? s.d_prog : j->d_prog;
     if (!(reuse && s.d_cpu && s.traces_valid)) {
@@ -513,14 +514,15 @@ static int shard_commit(dvt_prover *p, const dvt_pk *pk, dvt_job *j, ShardJob &s
     std::vector<ChipTrace> traces;
     // keep the phase-1 results in HBM while they fit (about 3 GB per 2^21-cycle shard); otherwise phase 2 recomputes
     size_t free_b = 0, total_b = 0;
-    if (p->keep_phase1 && !s.cache.tree) (void)hipMemGetInfo(&free_b, &total_b);   // (only the first commit of a shard asks)
+    if (p->keep_phase1 && !s.cache.tree) { (void)hipMemGetInfo(&free_b, &total_b); free_b += p->eng.pool.cached_bytes; }   // (only the first commit of a shard asks)
     MainCache *keep = p->keep_phase1 && (s.cache.tree || free_b > ((size_t)24 << 30)) ? &s.cache : nullptr;
     if (keep && !s.d_cpu) {
-        bool ok = hipMalloc(&s.d_cpu, ((size_t)RV32_CPU_MAIN_W << s.log_n[RV32_CHIP_CPU]) * 4) == hipSuccess && hipMalloc(&s.d_byte, j->byte_words * 4) == hipSuccess &&
-                  hipMalloc(&s.d_prog, j->prog_words * 4) == hipSuccess;
+        DevPool &pool = p->eng.pool;
+        bool ok = pool.alloc(&s.d_cpu, ((size_t)RV32_CPU_MAIN_W << s.log_n[RV32_CHIP_CPU]) * 4) == hipSuccess && pool.alloc(&s.d_byte, j->byte_words * 4) == hipSuccess &&
+                  pool.alloc(&s.d_prog, j->prog_words * 4) == hipSuccess;
         if (!ok) {  // not fatal: fall back to the shared working buffers
             (void)hipGetLastError();
-            for (uint32_t **d : {&s.d_cpu, &s.d_byte, &s.d_prog}) { if (*d) (void)hipFree(*d); *d = nullptr; }
+            for (uint32_t **d : {&s.d_cpu, &s.d_byte, &s.d_prog}) { pool.free(*d); *d = nullptr; }
         }
     }
     int rc = shard_traces(p, pk, j, s, &traces, false);
@@ -701,13 +703,13 @@ static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_buf
         ShardJob &s = j->shards.back();
         s.index = r.meta.index; s.n_recs = r.meta.n_recs; s.next_pc = r.meta.next_pc;
         for (int c = 0; c < m->n_chips; c++) { s.log_n[c] = r.aux.log_n[c]; s.present[c] = r.aux.present[c]; }
-        HIP_TRY(p, hipMalloc(&s.d_recs, s.n_recs * sizeof(rv32::CycleRec)));
+        HIP_TRY(p, p->eng.pool.alloc(&s.d_recs, s.n_recs * sizeof(rv32::CycleRec)));
         HIP_TRY(p, hipMemcpyAsync(s.d_recs, r.buf, s.n_recs * sizeof(rv32::CycleRec), hipMemcpyHostToDevice, p->copy_stream));
         HIP_TRY(p, hipEventRecord(ev, p->copy_stream));
         for (int c = 0; c < m->n_chips; c++) {
             if (c == RV32_CHIP_CPU || !s.present[c]) continue;
             size_t words = r.aux.main[c].size();
-            HIP_TRY(p, hipMalloc(&s.d_aux[c], words * 4));
+            HIP_TRY(p, p->eng.pool.alloc(&s.d_aux[c], words * 4));
             HIP_TRY(p, hipMemcpyAsync(s.d_aux[c], r.aux.main[c].data(), words * 4, hipMemcpyHostToDevice, p->eng.stream));
             // byte / program multiplicities stay plain integers until K0 has added the cpu rows' lookups
             if (c != RV32_CHIP_BYTE && c != RV32_CHIP_PROGRAM) HIP_TRY(p, launch_to_internal(p->eng.stream, s.d_aux[c], words));
@@ -785,7 +787,7 @@ static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_buf
     } else if (pl.unsupported && rc == DVT_ERR_GUEST) {
         rc = fail(p, DVT_ERR_UNSUPPORTED, "no chip for %s", pl.unsupported_what.c_str());
     }
-    if (rc) { job_release(j); return rc; }
+    if (rc) { job_release(p, j); return rc; }
     j->exit_code = pl.exit_code;
     j->cycles = pl.cycles;
     j->public_values = std::move(pl.public_values);
@@ -938,7 +940,7 @@ void dvt_job_free(dvt_prover *p, dvt_job *job) {
     if (!p || !job) return;
     std::lock_guard<std::mutex> lk(p->mu);
     (void)hipSetDevice(p->eng.device);
-    job_release(job);
+    job_release(p, job);
 }
 size_t dvt_rv32_job_shards(const dvt_job *job) { return job ? job->n_total : 0; }
 double dvt_rv32_job_exec_wait_seconds(const dvt_job *job) { return job ? job->t_exec_wait : 0.0; }
@@ -1006,7 +1008,7 @@ int dvt_prove_core(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_bufs, s
     int rc = job_prepare(p, pk, stdin_bufs, nbuf, 0, 1, &j, report);
     if (rc) return rc;
     rc = job_prove(p, pk, j, proof, proof_len);
-    job_release(j);
+    job_release(p, j);
     return rc;
 }
 

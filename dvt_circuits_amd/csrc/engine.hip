@@ -82,6 +82,7 @@ void Engine::shutdown() {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     arena.release();
+    pool.trim();
     ntt_tables_destroy(&tabs);
     if (d_ring) (void)hipFree(d_ring);
     if (h_ring) (void)hipHostFree(h_ring);
@@ -285,7 +286,7 @@ bool Engine::commit_main_root(const ProvingKey &pk, const std::vector<ChipTrace>
         max_log_n = std::max(max_log_n, t.log_n);
     }
     need += max_mat_words * 4 + (((size_t)4 << max_log_n)) * 32 + (1u << 20);
-    if (arena.cap < need) HIPCHK(arena.reserve(need + need / 8));
+    if (arena.cap < need && arena.reserve(need + need / 8) != hipSuccess) { (void)hipGetLastError(); pool.trim(); HIPCHK(arena.reserve(need + need / 8)); }
     uint32_t *d_scratch = arena.alloc<uint32_t>(max_mat_words);
     if (!d_scratch) return fail("commit: device arena exhausted");
     std::vector<DevMat> mats;
@@ -294,7 +295,7 @@ bool Engine::commit_main_root(const ProvingKey &pk, const std::vector<ChipTrace>
         std::vector<size_t> want;
         for (auto &t : traces) want.push_back(((size_t)m->chips[t.chip_id].main_w << t.log_n) * 2);
         reuse = keep->fits(want, max_log_n + 1);
-        if (!reuse) { keep->release(); keep->lde_words = want; }
+        if (!reuse) { keep->release(); keep->lde_words = want; keep->pool = &pool; }
         keep->valid = false;
     }
     size_t ti = 0;
@@ -304,7 +305,7 @@ bool Engine::commit_main_root(const ProvingKey &pk, const std::vector<ChipTrace>
         if (keep && reuse) {
             lde = keep->lde[ti];
         } else if (keep) {
-            HIPCHK(hipMalloc(&lde, ((size_t)d.main_w << t.log_n) * 8));
+            HIPCHK(pool.alloc(&lde, ((size_t)d.main_w << t.log_n) * 8));
             keep->lde.push_back(lde);
         } else {
             lde = arena.alloc<uint32_t>(((size_t)d.main_w << t.log_n) * 2);
@@ -327,7 +328,7 @@ bool Engine::commit_main_root(const ProvingKey &pk, const std::vector<ChipTrace>
     if (keep && reuse) {
         tree = keep->tree;
     } else if (keep) {
-        HIPCHK(hipMalloc(&tree, (((size_t)2 << hmax) - 1) * 32));
+        HIPCHK(pool.alloc(&tree, (((size_t)2 << hmax) - 1) * 32));
         keep->tree = tree;
         keep->log_h = hmax;
     } else {
@@ -443,7 +444,7 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
     need += 3 * tree_words(hmax) * 4;
     need += ((size_t)1 << hmax) * 16 * 4 + 2 * tree_words(hmax) * 4;
     need += ((size_t)1 << max_log_n) * 16 * 3 + (64u << 20);
-    if (arena.cap < need) HIPCHK(arena.reserve(need + need / 8));
+    if (arena.cap < need && arena.reserve(need + need / 8) != hipSuccess) { (void)hipGetLastError(); pool.trim(); HIPCHK(arena.reserve(need + need / 8)); }
 #define ALLOC(var, T, count)                                                        \
     do {                                                                            \
         var = arena.alloc<T>(count);                                                \

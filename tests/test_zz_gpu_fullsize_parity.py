@@ -23,7 +23,7 @@ def test_full_size_shard_bytes_equal_oracle():
     p = capi.Prover("{}")
     pk, vk = p.setup(elf)
     proof, rep = p.prove_core(pk, [buf])
-    assert (1 << 21) - 8192 < rep["cycles"] <= 1 << 21
+    assert (1 << 21) - 16384 < rep["cycles"] <= 1 << 21
     ok, ec, pv, why = capi.verify(vk, proof)
     assert ok and pv == guests.dkg_like_expected(buf, "finalization", *consts), why
     w = np.frombuffer(proof, np.uint32)
