@@ -263,6 +263,9 @@ def main():
     resident = 3 * int(rep1["cycles"]) / (time.perf_counter() - t1)
     prover.job_free(job1)
     prover.pk_free(pk1)
+    # the host executor alone on this box's cores (the sequential fast pass is the Amdahl term of the N-GPU prove)
+    extra["executor_fast_pass_cycles_per_s"] = capi.exec_rate(elf1, [stdin_buf], LOG_SHARD, False)
+    extra["executor_trace_mode_cycles_per_s_per_thread"] = capi.exec_rate(elf1, [stdin_buf], LOG_SHARD, True)
     prof = capi.Prover('{"device": %d, "fri_queries": 100, "pow_bits": 16, "profile": 1}' % local)
     ppk, _ = prof.setup(elf1)
     pjob, _ = prof.prepare(ppk, [stdin_buf])

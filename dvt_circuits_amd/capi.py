@@ -81,6 +81,8 @@ def load():
     lib.dvt_setup.argtypes = [vp, C.c_char_p, sz, C.POINTER(vp), C.POINTER(u8p), C.POINTER(sz)]
     lib.dvt_execute.argtypes = [C.c_char_p, sz, C.POINTER(Buf), sz, C.c_uint64, C.POINTER(u8p), C.POINTER(sz), C.POINTER(Report), C.POINTER(C.c_char_p)]
     lib.dvt_execute_io.argtypes = [C.c_char_p, sz, C.POINTER(Buf), sz, C.c_uint64, C.POINTER(u8p), C.POINTER(sz), C.POINTER(u8p), C.POINTER(sz), C.POINTER(Report), C.POINTER(C.c_char_p)]
+    lib.dvt_debug_exec_rate.argtypes = [C.c_char_p, sz, C.POINTER(Buf), sz, u32, C.c_int]
+    lib.dvt_debug_exec_rate.restype = C.c_double
     lib.dvt_prove_core.argtypes = [vp, vp, C.POINTER(Buf), sz, C.POINTER(u8p), C.POINTER(sz), C.POINTER(Report)]
     lib.dvt_verify.argtypes = [C.c_char_p, sz, C.c_char_p, sz, u32, u32, C.POINTER(C.c_int32), C.POINTER(u8p), C.POINTER(sz), C.POINTER(C.c_char_p)]
     lib.dvt_rv32_prepare.argtypes = [vp, vp, C.POINTER(Buf), sz, C.POINTER(vp), C.POINTER(Report)]
@@ -135,6 +137,11 @@ def execute(elf: bytes, stdin=(), max_cycles=0):
     if pv:
         lib.dvt_free(C.cast(pv, C.c_void_p))
     return rc, dict(cycles=rep.cycles, exit_code=rep.exit_code, halted=bool(rep.halted), unprovable=bool(rep.unprovable)), out, _take_str(lib, err)
+
+
+def exec_rate(elf: bytes, stdin=(), log_shard=21, trace=False) -> float:
+    """guest cycles / second of the host executor alone (fast or trace mode)"""
+    return float(load().dvt_debug_exec_rate(elf, len(elf), _bufs(stdin), len(stdin), log_shard, int(trace)))
 
 
 def execute_io(elf: bytes, stdin=(), max_cycles=0):

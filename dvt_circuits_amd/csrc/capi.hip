@@ -1184,6 +1184,27 @@ int dvt_rv32_debug_device_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *j, si
     return DVT_OK;
 }
 
+// measurement hook (host only): guest cycles per second of the executor alone, fast mode (trace = 0: what the
+// sequential pass of the prove pipeline runs) or trace mode (one 48-byte record per cycle into a reused buffer)
+double dvt_debug_exec_rate(const uint8_t *elf, size_t elf_len, const dvt_buf *stdin_bufs, size_t nbuf, uint32_t log_shard, int trace) {
+    rv32::Program prog;
+    std::string err;
+    if (!elf || !rv32::load_elf(elf, elf_len, &prog, &err)) return 0.0;
+    const std::vector<std::vector<uint8_t>> inputs = collect_stdin(stdin_bufs, nbuf);
+    std::vector<rv32::CycleRec> buf;
+    if (trace) buf.resize((size_t)1 << log_shard);
+    rv32::ShardOut out;
+    out.recs = buf.data();
+    const auto t0 = std::chrono::steady_clock::now();
+    rv32::Vm vm(prog, &inputs, log_shard);
+    for (;;) {
+        vm.run_shard(trace != 0, &out, ~0ull);
+        if (vm.halted || !vm.error.empty() || !vm.next_shard()) break;
+    }
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return vm.halted ? (double)vm.cycles / dt : 0.0;
+}
+
 // test hook (host only): the FP64 formulation of Poseidon2 that the hashing kernels run, evaluated on the host
 // (IEEE doubles + fma, the same arithmetic) against the integer permutation on n pseudo-random and edge-case states,
 // through the same Montgomery conversions the kernels use.  Returns the number of differing words.

@@ -47,16 +47,28 @@ constexpr uint32_t ALU_MULH = 4, ALU_MULHSU = 5, ALU_DIV = 6, ALU_DIVU = 7, ALU_
 constexpr int N_CHIPS = 7;  // program, byte, cpu, mem_image, mem_init, shift, muldiv
 constexpr uint32_t N_PUBLIC = 5;  // start_pc, next_pc, exit_code, shard, is_last
 
+// dense dispatch code of the interpreter (one case per instruction form: which ports it drives is static per case)
+enum Kind : uint8_t {
+    K_UNSUP, K_ADD, K_SUB, K_AND, K_OR, K_XOR, K_SLT, K_SLTU, K_MUL, K_MULHU,       // register forms: rs1, rs2 -> rd
+    K_ADDI, K_ANDI, K_ORI, K_XORI, K_SLTI, K_SLTIU,                                 // immediate forms: rs1, imm -> rd
+    K_LUI, K_JAL, K_JALR, K_BEQ, K_BNE, K_BLT, K_BGE, K_BLTU, K_BGEU,
+    K_LW, K_LB, K_LBU, K_LH, K_LHU, K_SW, K_SB, K_SH, K_ALU_R, K_ALU_I, K_ECALL,
+    K_OOB,   // the sentinel after the last instruction of the text: control reached an address outside it
+    N_KINDS
+};
+
 struct Instr {
     uint32_t pc, rd, rs1, rs2, imm, off, tgt, flags;
     uint32_t alu_op;  // for F_ALU instructions: which chip / operation receives (a, b, c)
     uint32_t raw;
     uint8_t supported;  // has a chip (otherwise executes only)
+    uint8_t kind;       // Kind
+    uint32_t tgt_idx;   // branches / JAL: index of the target in Program::instrs (the sentinel's when it lies outside the text)
 };
 
 struct Program {
     uint32_t entry = 0, text_base = 0;
-    std::vector<Instr> instrs;                            // index (pc - text_base) / 4
+    std::vector<Instr> instrs;                            // index (pc - text_base) / 4, plus one K_OOB sentinel at the end
     std::vector<std::pair<uint32_t, uint32_t>> image;     // (byte address, word), sorted, word aligned
 };
 
@@ -115,7 +127,13 @@ bool load_elf(const uint8_t *elf, size_t n, Program *out, std::string *err);
 // from the snapshots in trace mode on other threads (capi.hip), overlapped with the GPU.
 // Guest memory is paged copy-on-write: a snapshot shares every page the next shard does not touch.
 constexpr uint32_t PAGE_WORD_BITS = 12;
-struct Cell { uint32_t val, ts, sh, flags; };   // flags: 1 = accessed by a load / store, 2 = part of the program image
+// flags: 1 = accessed by a load / store, 2 = part of the program image; tsh = clk | shard << 32 of the last access
+struct Cell {
+    uint32_t val, flags;
+    uint64_t tsh;
+    uint32_t ts() const { return (uint32_t)tsh; }
+    uint32_t sh() const { return (uint32_t)(tsh >> 32); }
+};
 struct Page { Cell c[1u << PAGE_WORD_BITS]; };
 constexpr uint32_t N_PAGES = 1u << (30 - 2 - PAGE_WORD_BITS);
 

@@ -93,6 +93,40 @@ static Instr decode(uint32_t w, uint32_t pc) {
     case 0x0f: in.supported = 0; break;  // fence
     default: in.supported = 0; break;
     }
+    // dispatch code of the interpreter
+    const uint32_t fl = in.flags;
+    const bool immf = fl & FL(F_IMM_C);
+    uint8_t k = K_UNSUP;
+    if (!in.supported) k = K_UNSUP;
+    else if (fl & FL(F_ADD)) k = immf ? K_ADDI : K_ADD;
+    else if (fl & FL(F_SUB)) k = K_SUB;
+    else if (fl & FL(F_AND)) k = immf ? K_ANDI : K_AND;
+    else if (fl & FL(F_OR)) k = immf ? K_ORI : K_OR;
+    else if (fl & FL(F_XOR)) k = immf ? K_XORI : K_XOR;
+    else if (fl & FL(F_SLT)) k = immf ? K_SLTI : K_SLT;
+    else if (fl & FL(F_SLTU)) k = immf ? K_SLTIU : K_SLTU;
+    else if (fl & FL(F_MUL)) k = K_MUL;
+    else if (fl & FL(F_MULHU)) k = K_MULHU;
+    else if (fl & FL(F_LUI)) k = K_LUI;
+    else if (fl & FL(F_JAL)) k = K_JAL;
+    else if (fl & FL(F_JALR)) k = K_JALR;
+    else if (fl & FL(F_BEQ)) k = K_BEQ;
+    else if (fl & FL(F_BNE)) k = K_BNE;
+    else if (fl & FL(F_BLT)) k = K_BLT;
+    else if (fl & FL(F_BGE)) k = K_BGE;
+    else if (fl & FL(F_BLTU)) k = K_BLTU;
+    else if (fl & FL(F_BGEU)) k = K_BGEU;
+    else if (fl & FL(F_LW)) k = K_LW;
+    else if (fl & FL(F_LB)) k = K_LB;
+    else if (fl & FL(F_LBU)) k = K_LBU;
+    else if (fl & FL(F_LH)) k = K_LH;
+    else if (fl & FL(F_LHU)) k = K_LHU;
+    else if (fl & FL(F_SW)) k = K_SW;
+    else if (fl & FL(F_SB)) k = K_SB;
+    else if (fl & FL(F_SH)) k = K_SH;
+    else if (fl & FL(F_ALU)) k = immf ? K_ALU_I : K_ALU_R;
+    else if (fl & FL(F_ECALL)) k = K_ECALL;
+    in.kind = k;
     return in;
 }
 
@@ -129,12 +163,21 @@ bool load_elf(const uint8_t *elf, size_t n, Program *out, std::string *err) {
             have_text = true;
             p.text_base = vaddr;
             uint32_t words = (filesz + 3) / 4;
-            p.instrs.resize(words);
+            p.instrs.resize(words + 1);
             for (uint32_t k = 0; k < words; k++) p.instrs[k] = decode(image[vaddr + 4 * k], vaddr + 4 * k);
+            // sentinel: where sequential flow past the end and every static target outside the text land
+            Instr oob{};
+            oob.pc = vaddr + 4 * words; oob.kind = K_OOB; oob.supported = 0; oob.tgt_idx = words;
+            p.instrs[words] = oob;
+            for (uint32_t k = 0; k < words; k++) {
+                Instr &in = p.instrs[k];
+                const uint32_t t = in.tgt - vaddr;
+                in.tgt_idx = (in.tgt >= vaddr && t % 4 == 0 && t / 4 < words) ? t / 4 : words;
+            }
         }
     }
     if (!have_text) return bad("no executable segment");
-    if (p.entry < p.text_base || p.entry >= p.text_base + 4 * p.instrs.size() || p.entry % 4) return bad("entry point outside text");
+    if (p.entry < p.text_base || p.entry >= p.text_base + 4 * (p.instrs.size() - 1) || p.entry % 4) return bad("entry point outside text");
     p.image.assign(image.begin(), image.end());
     *out = std::move(p);
     return true;
@@ -145,7 +188,7 @@ static constexpr uint32_t FL_TOUCHED = 1, FL_IMG = 2;
 
 Vm::Vm(const Program &p, const std::vector<std::vector<uint8_t>> *in, uint32_t ls)
     : prog(p), pc(p.entry), log_shard(ls), stdin_bufs(in), holders(N_PAGES), raw(N_PAGES, nullptr), own(N_PAGES, 0) {
-    for (auto &c : regs) c = Cell{0, 0, 0, FL_IMG};
+    for (auto &c : regs) c = Cell{0, FL_IMG, 0};
     for (auto &kv : prog.image)
         if (kv.first >= 32) { Cell &c = at(kv.first); c.val = kv.second; c.flags = FL_IMG; }
 }
@@ -208,158 +251,213 @@ void Vm::run_shard(bool trace, ShardOut *out, uint64_t max_total_cycles) {
     if (error.empty() && !halted && cycles >= max_total_cycles) error = "cycle limit reached before HALT";
 }
 
+// Threaded interpreter: every instruction form has its own handler that ends in its own indirect jump to the next
+// handler (one predictor entry per form instead of one shared dispatch branch), the text is walked by instruction
+// pointer (static targets are pre-resolved to indices, a K_OOB sentinel after the last instruction catches control
+// leaving the text), and an access stamps its (shard, clk) pair with one 64-bit store.
 template <bool TRACE>
 void Vm::run(ShardOut *out, uint64_t budget) {
     const Instr *const code = prog.instrs.data();
-    const uint32_t ninstr = (uint32_t)prog.instrs.size(), text_base = prog.text_base;
-    const uint32_t sh = shard;
+    const uint32_t ninstr = (uint32_t)prog.instrs.size() - 1, text_base = prog.text_base;
+    const uint64_t sh64 = (uint64_t)shard << 32;
     CycleRec *recs = TRACE ? out->recs + out->n_recs : nullptr;
     uint64_t done = 0;
-    uint32_t lpc = pc;
-    constexpr uint32_t MEM_FAMILY = FL(F_LW) | FL(F_SW) | FL(F_LB) | FL(F_LBU) | FL(F_LH) | FL(F_LHU) | FL(F_SB) | FL(F_SH);
-    constexpr uint32_t BRANCHES = FL(F_BEQ) | FL(F_BNE) | FL(F_BLT) | FL(F_BGE) | FL(F_BLTU) | FL(F_BGEU);
-    auto fail = [&](const char *m) { pc = lpc; trap(m); };
-    while (done < budget) {
-        const uint32_t idx = (lpc - text_base) >> 2;
-        if (idx >= ninstr || (lpc & 3) || lpc < text_base) { fail("pc outside text"); break; }
-        const Instr &in = code[idx];
-        const uint32_t fl = in.flags;
-        const uint32_t clk = 4 * (in_shard + 1);
-        if (__builtin_expect(!in.supported, 0)) {
-            // FENCE retires as a no-op (no chip: the run cannot be proven); everything else without a chip is illegal
-            if ((in.raw & 0x7f) != 0x0f) { fail("illegal instruction"); break; }
-            if (!unsupported) { char bb[64]; snprintf(bb, sizeof bb, "instruction 0x%08x at pc 0x%x", in.raw, lpc); unsupported_what = bb; }
-            unsupported = true;
-            if (TRACE) { fail("instruction without a chip in a traced run"); break; }
-            lpc += 4; done++; in_shard++;
-            continue;
-        }
-        CycleRec rec;
-        uint32_t sha = 0, shb = 0, shc = 0, shm = 0;
-        if (TRACE) { rec.idx = idx; rec.pa_prev = rec.pa_ts = rec.pb_ts = rec.pc_ts = rec.m_prev = rec.m_ts = 0; }
-        uint32_t next_pc = lpc + 4, a = 0, b = 0, c = 0;
-        // ---- accesses in port order: c (rs2) at clk, b (rs1) at clk + 1, memory at clk + 2, a (rd) at clk + 3
-        if (fl & FL(F_RS2_EN)) { Cell &r2 = regs[in.rs2]; c = r2.val; if (TRACE) { rec.pc_ts = r2.ts; shc = r2.sh; } r2.ts = clk; r2.sh = sh; }
-        if (fl & FL(F_IMM_C)) c = in.imm;
-        if (fl & FL(F_RS1_EN)) { Cell &r1 = regs[in.rs1]; b = r1.val; if (TRACE) { rec.pb_ts = r1.ts; shb = r1.sh; } r1.ts = clk + 1; r1.sh = sh; }
-        if (fl & FL(F_ADD)) a = b + c;
-        else if (fl & MEM_FAMILY) {
-            const uint32_t addr = b + in.off;
-            if (addr < 32 || addr >= ADDR_LIMIT) { fail("memory access out of range"); break; }
-            if ((fl & (FL(F_LW) | FL(F_SW))) && (addr & 3)) { fail("misaligned word access"); break; }
-            if ((fl & (FL(F_LH) | FL(F_LHU) | FL(F_SH))) && (addr & 1)) { fail("misaligned halfword access"); break; }
-            Cell &cell = at(addr & ~3u);
-            if (!(cell.flags & (FL_TOUCHED | FL_IMG))) { cell.flags |= FL_TOUCHED; if (collect_output) first_touch.emplace_back(addr & ~3u, cell.val); }
-            if (TRACE) { rec.m_prev = cell.val; rec.m_ts = cell.ts; shm = cell.sh; }
-            const uint32_t sh8 = 8 * (addr & 3);
-            if (fl & FL(F_LW)) a = cell.val;
-            else if (fl & FL(F_SW)) cell.val = c;
-            else if (fl & FL(F_SB)) cell.val = (cell.val & ~(0xffu << sh8)) | ((c & 0xff) << sh8);
-            else if (fl & FL(F_SH)) cell.val = (cell.val & ~(0xffffu << sh8)) | ((c & 0xffff) << sh8);
-            else if (fl & FL(F_LB)) a = sext((cell.val >> sh8) & 0xff, 8);
-            else if (fl & FL(F_LBU)) a = (cell.val >> sh8) & 0xff;
-            else if (fl & FL(F_LH)) a = sext((cell.val >> sh8) & 0xffff, 16);
-            else a = (cell.val >> sh8) & 0xffff;
-            cell.ts = clk + 2;
-            cell.sh = sh;
-        }
-        else if (fl & FL(F_SLTU)) a = b < c;
-        else if (fl & FL(F_MUL)) a = b * c;
-        else if (fl & FL(F_MULHU)) a = (uint32_t)(((uint64_t)b * c) >> 32);
-        else if (fl & BRANCHES) {
-            bool t = (fl & FL(F_BEQ)) ? b == c : (fl & FL(F_BNE)) ? b != c : (fl & FL(F_BLT)) ? (int32_t)b < (int32_t)c
-                   : (fl & FL(F_BGE)) ? (int32_t)b >= (int32_t)c : (fl & FL(F_BLTU)) ? b < c : b >= c;
-            if (t) next_pc = in.tgt;
-        }
-        else if (fl & FL(F_SUB)) a = b - c;
-        else if (fl & FL(F_AND)) a = b & c;
-        else if (fl & FL(F_OR)) a = b | c;
-        else if (fl & FL(F_XOR)) a = b ^ c;
-        else if (fl & FL(F_SLT)) a = (int32_t)b < (int32_t)c;
-        else if (fl & FL(F_LUI)) a = in.imm;
-        else if (fl & FL(F_ALU)) {
-            const uint32_t s5 = c & 31;
-            const int32_t sb = (int32_t)b, sc = (int32_t)c;
-            switch (in.alu_op) {
-            case ALU_SLL: a = b << s5; break;
-            case ALU_SRL: a = b >> s5; break;
-            case ALU_SRA: a = (uint32_t)(sb >> s5); break;
-            case ALU_MULH: a = (uint32_t)(((int64_t)sb * (int64_t)sc) >> 32); break;
-            case ALU_MULHSU: a = (uint32_t)(((int64_t)sb * (int64_t)(uint64_t)c) >> 32); break;
-            // RISC-V: x / 0 = all ones, x % 0 = x; -2^31 / -1 = -2^31 remainder 0
-            case ALU_DIV: a = c == 0 ? 0xffffffffu : (b == 0x80000000u && c == 0xffffffffu) ? b : (uint32_t)(sb / sc); break;
-            case ALU_DIVU: a = c == 0 ? 0xffffffffu : b / c; break;
-            case ALU_REM: a = c == 0 ? b : (b == 0x80000000u && c == 0xffffffffu) ? 0u : (uint32_t)(sb % sc); break;
-            default: a = c == 0 ? b : b % c; break;  // ALU_REMU
-            }
-            if (TRACE) out->alu.push_back(AluEvent{in.alu_op, a, b, c});
-        }
-        else if (fl & FL(F_JAL)) { a = in.imm; next_pc = in.tgt; }
-        else if (fl & FL(F_JALR)) {
-            a = in.imm;
-            const uint32_t t = b + in.off;
-            if (t >= ADDR_LIMIT) { fail("jump target out of range"); break; }
-            next_pc = t & ~1u;
-        } else if (fl & FL(F_ECALL)) {
-            // b = t0 (id), c = a0; a1 / a2 are read without a port except by COMMIT
-            const uint32_t a1 = regs[11].val, a2 = regs[12].val;
-            a = b;  // t0 unchanged unless the call returns a value
-            bool bad = false;
-            switch (b) {
-            case 0x00: halted = true; exit_code = (int)c; next_pc = 0; break;
-            case 0x02: {  // WRITE(fd = a0, ptr = a1, len = a2): fd 3 = the public-value stream
-                if ((uint64_t)a1 + a2 > ADDR_LIMIT) { fail("WRITE buffer out of range"); bad = true; break; }
-                if (!collect_output) break;
-                std::vector<uint8_t> &dst = c == 3 ? public_values : stdout_bytes;
-                for (uint32_t k = 0; k < a2; k++) {
-                    const uint32_t ad = a1 + k;
-                    const Cell *cell = ad >= 32 ? peek(ad & ~3u) : nullptr;
-                    dst.push_back(cell ? (uint8_t)(cell->val >> (8 * (ad & 3))) : 0);
-                }
-                break;
-            }
-            case SYS_COMMIT: {  // COMMIT(a0 = index, a1 = word): a1 is read through the memory port
-                Cell &r11 = regs[REG_A1];
-                if (TRACE) { rec.m_prev = r11.val; rec.m_ts = r11.ts; shm = r11.sh; }
-                r11.ts = clk + 2;
-                r11.sh = sh;
-                if (c < 8) { committed[c] = a1; committed_mask |= 1u << c; }
-                break;
-            }
-            case 0x1a: break;  // COMMIT_DEFERRED_PROOFS: no-op (no recursion in core proofs)
-            case 0xf0: a = next_input < stdin_bufs->size() ? (uint32_t)(*stdin_bufs)[next_input].size() : 0; break;
-            case 0xf1: {  // HINT_READ(ptr = a0, len = a1): the words become initial memory (must be untouched so far)
-                if (next_input >= stdin_bufs->size()) { fail("HINT_READ with no input left"); bad = true; break; }
-                const auto &buf = (*stdin_bufs)[next_input++];
-                if (a1 != buf.size()) { fail("HINT_READ length mismatch"); bad = true; break; }
-                if (c % 4 || c < 32 || (uint64_t)c + a1 > ADDR_LIMIT) { fail("HINT_READ pointer misaligned or out of range"); bad = true; break; }
-                for (uint32_t k = 0; k < a1; k += 4) {
-                    Cell &cell = at(c + k);
-                    if (cell.flags || cell.sh) { fail("HINT_READ into the program image or into memory that was already accessed"); bad = true; break; }
-                    uint32_t wv = 0;
-                    for (uint32_t q = 0; q < 4 && k + q < a1; q++) wv |= (uint32_t)buf[k + q] << (8 * q);
-                    cell.val = wv;
-                }
-                break;
-            }
-            default: fail("unknown syscall"); bad = true; break;
-            }
-            if (bad) break;
-        }
-        if (fl & FL(F_RD_EN)) { Cell &rdc = regs[in.rd]; if (TRACE) { rec.pa_prev = rdc.val; rec.pa_ts = rdc.ts; sha = rdc.sh; } rdc.val = a; rdc.ts = clk + 3; rdc.sh = sh; }
-        if (TRACE) {
-            rec.a = a; rec.b = b; rec.c = c;
-            rec.sh_ab = sha | (shb << 16);
-            rec.sh_cm = shc | (shm << 16);
-            recs[done] = rec;
-        }
-        done++;
-        in_shard++;
-        lpc = next_pc;
-        if (halted) break;
+    uint32_t clk = 4 * (in_shard + 1);
+    const Instr *ip;
+    {
+        const uint32_t idx0 = (pc - text_base) >> 2;
+        ip = code + ((pc >= text_base && !(pc & 3) && idx0 < ninstr) ? idx0 : ninstr);
     }
-    if (error.empty()) pc = lpc;
+    const Instr *nip = ip, *prev = nullptr;
+    uint32_t jump_pc = 0;
+    CycleRec rec;
+    uint32_t sha = 0, shb = 0, shc = 0, shm = 0, a = 0, b = 0, c = 0, addr = 0, s8 = 0;
+    Cell *cellp = nullptr;
+    const char *why = nullptr;
+    static const void *const handlers[N_KINDS] = {
+        &&L_UNSUP, &&L_ADD, &&L_SUB, &&L_AND, &&L_OR, &&L_XOR, &&L_SLT, &&L_SLTU, &&L_MUL, &&L_MULHU,
+        &&L_ADDI, &&L_ANDI, &&L_ORI, &&L_XORI, &&L_SLTI, &&L_SLTIU,
+        &&L_LUI, &&L_JAL, &&L_JALR, &&L_BEQ, &&L_BNE, &&L_BLT, &&L_BGE, &&L_BLTU, &&L_BGEU,
+        &&L_LW, &&L_LB, &&L_LBU, &&L_LH, &&L_LHU, &&L_SW, &&L_SB, &&L_SH, &&L_ALU, &&L_ALU, &&L_ECALL, &&L_OOB};
+    // ports in time order: c (rs2) at clk, b (rs1) at clk + 1, memory at clk + 2, a (rd) at clk + 3; each access leaves
+    // its (shard, clk) on the word and, in trace mode, records the pair it found there
+#define IN (*ip)
+#define PORT_C() do { Cell &r2_ = regs[IN.rs2]; c = r2_.val; if (TRACE) { rec.pc_ts = r2_.ts(); shc = r2_.sh(); } r2_.tsh = sh64 | clk; } while (0)
+#define PORT_B() do { Cell &r1_ = regs[IN.rs1]; b = r1_.val; if (TRACE) { rec.pb_ts = r1_.ts(); shb = r1_.sh(); } r1_.tsh = sh64 | (clk + 1); } while (0)
+#define PORT_A(v) do { if (IN.rd) { Cell &rd_ = regs[IN.rd]; if (TRACE) { rec.pa_prev = rd_.val; rec.pa_ts = rd_.ts(); sha = rd_.sh(); } rd_.val = (v); rd_.tsh = sh64 | (clk + 3); } } while (0)
+#define MEM(align_mask, what) do { addr = b + IN.off; \
+        if (__builtin_expect(addr < 32 || addr >= ADDR_LIMIT, 0)) { why = "memory access out of range"; goto trapped; } \
+        if (__builtin_expect(addr & (align_mask), 0)) { why = what; goto trapped; } \
+        cellp = &at(addr & ~3u); \
+        if (!(cellp->flags & (FL_TOUCHED | FL_IMG))) { cellp->flags |= FL_TOUCHED; if (collect_output) first_touch.emplace_back(addr & ~3u, cellp->val); } \
+        if (TRACE) { rec.m_prev = cellp->val; rec.m_ts = cellp->ts(); shm = cellp->sh(); } \
+        cellp->tsh = sh64 | (clk + 2); s8 = 8 * (addr & 3); } while (0)
+#define BEGIN() do { if (TRACE) { rec.idx = (uint32_t)(ip - code); rec.pa_prev = rec.pa_ts = rec.pb_ts = rec.pc_ts = rec.m_prev = rec.m_ts = 0; sha = shb = shc = shm = 0; } } while (0)
+#define NEXT() do { \
+        if (TRACE) { rec.a = a; rec.b = b; rec.c = c; rec.sh_ab = sha | (shb << 16); rec.sh_cm = shc | (shm << 16); recs[done] = rec; } \
+        done++; clk += 4; prev = ip; ip = nip; \
+        if (__builtin_expect(done >= budget, 0)) goto out_of_budget; \
+        goto *handlers[ip->kind]; } while (0)
+#define SEQ() do { nip = ip + 1; NEXT(); } while (0)
+#define RRR(expr) do { BEGIN(); PORT_C(); PORT_B(); a = (expr); PORT_A(a); SEQ(); } while (0)
+#define RRI(expr) do { BEGIN(); c = IN.imm; PORT_B(); a = (expr); PORT_A(a); SEQ(); } while (0)
+#define BRANCH(cond) do { BEGIN(); PORT_C(); PORT_B(); a = 0; nip = (cond) ? code + IN.tgt_idx : ip + 1; NEXT(); } while (0)
+    if (budget == 0) goto out_of_budget;
+    goto *handlers[ip->kind];
+L_ADD: RRR(b + c);
+L_SUB: RRR(b - c);
+L_AND: RRR(b & c);
+L_OR: RRR(b | c);
+L_XOR: RRR(b ^ c);
+L_SLT: RRR((uint32_t)((int32_t)b < (int32_t)c));
+L_SLTU: RRR((uint32_t)(b < c));
+L_MUL: RRR(b * c);
+L_MULHU: RRR((uint32_t)(((uint64_t)b * c) >> 32));
+L_ADDI: RRI(b + c);
+L_ANDI: RRI(b & c);
+L_ORI: RRI(b | c);
+L_XORI: RRI(b ^ c);
+L_SLTI: RRI((uint32_t)((int32_t)b < (int32_t)c));
+L_SLTIU: RRI((uint32_t)(b < c));
+L_LUI: BEGIN(); b = c = 0; a = IN.imm; PORT_A(a); SEQ();
+L_JAL: BEGIN(); b = c = 0; a = IN.imm; PORT_A(a); nip = code + IN.tgt_idx; NEXT();
+L_JALR: {
+    BEGIN(); c = 0; PORT_B();
+    a = IN.imm;
+    const uint32_t t = b + IN.off;
+    if (__builtin_expect(t >= ADDR_LIMIT, 0)) { why = "jump target out of range"; goto trapped; }
+    const uint32_t tp = t & ~1u, ti = (tp - text_base) >> 2;
+    PORT_A(a);
+    nip = code + ((tp >= text_base && !(tp & 3) && ti < ninstr) ? ti : ninstr);
+    if (nip == code + ninstr) jump_pc = tp;   // (reported by the sentinel's trap)
+    NEXT();
+}
+L_BEQ: BRANCH(b == c);
+L_BNE: BRANCH(b != c);
+L_BLT: BRANCH((int32_t)b < (int32_t)c);
+L_BGE: BRANCH((int32_t)b >= (int32_t)c);
+L_BLTU: BRANCH(b < c);
+L_BGEU: BRANCH(b >= c);
+L_LW: BEGIN(); c = 0; PORT_B(); MEM(3, "misaligned word access"); a = cellp->val; PORT_A(a); SEQ();
+L_LB: BEGIN(); c = 0; PORT_B(); MEM(0, ""); a = sext((cellp->val >> s8) & 0xff, 8); PORT_A(a); SEQ();
+L_LBU: BEGIN(); c = 0; PORT_B(); MEM(0, ""); a = (cellp->val >> s8) & 0xff; PORT_A(a); SEQ();
+L_LH: BEGIN(); c = 0; PORT_B(); MEM(1, "misaligned halfword access"); a = sext((cellp->val >> s8) & 0xffff, 16); PORT_A(a); SEQ();
+L_LHU: BEGIN(); c = 0; PORT_B(); MEM(1, "misaligned halfword access"); a = (cellp->val >> s8) & 0xffff; PORT_A(a); SEQ();
+L_SW: BEGIN(); PORT_C(); PORT_B(); MEM(3, "misaligned word access"); a = 0; cellp->val = c; SEQ();
+L_SB: BEGIN(); PORT_C(); PORT_B(); MEM(0, ""); a = 0; cellp->val = (cellp->val & ~(0xffu << s8)) | ((c & 0xff) << s8); SEQ();
+L_SH: BEGIN(); PORT_C(); PORT_B(); MEM(1, "misaligned halfword access"); a = 0; cellp->val = (cellp->val & ~(0xffffu << s8)) | ((c & 0xffff) << s8); SEQ();
+L_ALU: {
+    BEGIN();
+    if (IN.kind == K_ALU_R) PORT_C(); else c = IN.imm;
+    PORT_B();
+    const uint32_t s5 = c & 31;
+    const int32_t sb = (int32_t)b, sc = (int32_t)c;
+    switch (IN.alu_op) {
+    case ALU_SLL: a = b << s5; break;
+    case ALU_SRL: a = b >> s5; break;
+    case ALU_SRA: a = (uint32_t)(sb >> s5); break;
+    case ALU_MULH: a = (uint32_t)(((int64_t)sb * (int64_t)sc) >> 32); break;
+    case ALU_MULHSU: a = (uint32_t)(((int64_t)sb * (int64_t)(uint64_t)c) >> 32); break;
+    // RISC-V: x / 0 = all ones, x % 0 = x; -2^31 / -1 = -2^31 remainder 0
+    case ALU_DIV: a = c == 0 ? 0xffffffffu : (b == 0x80000000u && c == 0xffffffffu) ? b : (uint32_t)(sb / sc); break;
+    case ALU_DIVU: a = c == 0 ? 0xffffffffu : b / c; break;
+    case ALU_REM: a = c == 0 ? b : (b == 0x80000000u && c == 0xffffffffu) ? 0u : (uint32_t)(sb % sc); break;
+    default: a = c == 0 ? b : b % c; break;  // ALU_REMU
+    }
+    if (TRACE) out->alu.push_back(AluEvent{IN.alu_op, a, b, c});
+    PORT_A(a);
+    SEQ();
+}
+L_ECALL: {
+    // b = t0 (id), c = a0; a1 / a2 are read without a port except by COMMIT
+    BEGIN(); PORT_C(); PORT_B();
+    const uint32_t a1 = regs[11].val, a2 = regs[12].val;
+    a = b;  // t0 unchanged unless the call returns a value
+    nip = ip + 1;
+    switch (b) {
+    case 0x00: halted = true; exit_code = (int)c; break;
+    case 0x02: {  // WRITE(fd = a0, ptr = a1, len = a2): fd 3 = the public-value stream
+        if ((uint64_t)a1 + a2 > ADDR_LIMIT) { why = "WRITE buffer out of range"; goto trapped; }
+        if (!collect_output) break;
+        std::vector<uint8_t> &dst = c == 3 ? public_values : stdout_bytes;
+        for (uint32_t k = 0; k < a2; k++) {
+            const uint32_t ad = a1 + k;
+            const Cell *cell = ad >= 32 ? peek(ad & ~3u) : nullptr;
+            dst.push_back(cell ? (uint8_t)(cell->val >> (8 * (ad & 3))) : 0);
+        }
+        break;
+    }
+    case SYS_COMMIT: {  // COMMIT(a0 = index, a1 = word): a1 is read through the memory port
+        Cell &r11 = regs[REG_A1];
+        if (TRACE) { rec.m_prev = r11.val; rec.m_ts = r11.ts(); shm = r11.sh(); }
+        r11.tsh = sh64 | (clk + 2);
+        if (c < 8) { committed[c] = a1; committed_mask |= 1u << c; }
+        break;
+    }
+    case 0x1a: break;  // COMMIT_DEFERRED_PROOFS: no-op (no recursion in core proofs)
+    case 0xf0: a = next_input < stdin_bufs->size() ? (uint32_t)(*stdin_bufs)[next_input].size() : 0; break;
+    case 0xf1: {  // HINT_READ(ptr = a0, len = a1): the words become initial memory (must be untouched so far)
+        if (next_input >= stdin_bufs->size()) { why = "HINT_READ with no input left"; goto trapped; }
+        const auto &buf = (*stdin_bufs)[next_input++];
+        if (a1 != buf.size()) { why = "HINT_READ length mismatch"; goto trapped; }
+        if (c % 4 || c < 32 || (uint64_t)c + a1 > ADDR_LIMIT) { why = "HINT_READ pointer misaligned or out of range"; goto trapped; }
+        for (uint32_t k = 0; k < a1; k += 4) {
+            Cell &cell = at(c + k);
+            if (cell.flags || cell.tsh) { why = "HINT_READ into the program image or into memory that was already accessed"; goto trapped; }
+            uint32_t wv = 0;
+            for (uint32_t q = 0; q < 4 && k + q < a1; q++) wv |= (uint32_t)buf[k + q] << (8 * q);
+            cell.val = wv;
+        }
+        break;
+    }
+    default: why = "unknown syscall"; goto trapped;
+    }
+    PORT_A(a);
+    if (halted) {
+        if (TRACE) { rec.a = a; rec.b = b; rec.c = c; rec.sh_ab = sha | (shb << 16); rec.sh_cm = shc | (shm << 16); recs[done] = rec; }
+        done++;
+        pc = 0;
+        goto finished;
+    }
+    NEXT();
+}
+L_UNSUP: {
+    // FENCE retires as a no-op (no chip: the run cannot be proven); everything else without a chip is illegal
+    if ((IN.raw & 0x7f) != 0x0f) { why = "illegal instruction"; goto trapped; }
+    if (!unsupported) { char bb[64]; snprintf(bb, sizeof bb, "instruction 0x%08x at pc 0x%x", IN.raw, IN.pc); unsupported_what = bb; }
+    unsupported = true;
+    if (TRACE) { why = "instruction without a chip in a traced run"; goto trapped; }
+    done++; clk += 4; ip = ip + 1;
+    if (done >= budget) goto out_of_budget;
+    goto *handlers[ip->kind];
+}
+L_OOB:
+    // control left the text: report the address it went to (a JALR recorded it; a static jump's target is in `prev`)
+    if (jump_pc) pc = jump_pc;
+    else if (prev && prev->tgt_idx == ninstr && (prev->kind == K_JAL || (prev->kind >= K_BEQ && prev->kind <= K_BGEU && prev + 1 != ip))) pc = prev->tgt;
+    else pc = ip->pc;
+    trap("pc outside text");
+    goto finished;
+trapped:
+    pc = ip->pc;
+    trap(why);
+    goto finished;
+out_of_budget:
+    pc = ip->pc;
+finished:
+#undef IN
+#undef PORT_A
+#undef PORT_B
+#undef PORT_C
+#undef MEM
+#undef BEGIN
+#undef NEXT
+#undef SEQ
+#undef RRR
+#undef RRI
+#undef BRANCH
     cycles += done;
+    in_shard += (uint32_t)done;
     if (TRACE) out->n_recs += done;
 }
 
@@ -369,12 +467,12 @@ std::vector<MemInitRow> Vm::mem_rows() const {
     for (auto &kv : prog.image) {
         MemInitRow r{kv.first, kv.second, kv.second, 0, 0, 1};
         const Cell *c = kv.first < 32 ? &regs[kv.first] : peek(kv.first);
-        if (c && c->sh) { r.f = c->val; r.fts = c->ts; r.fsh = c->sh; }
+        if (c && c->tsh) { r.f = c->val; r.fts = c->ts(); r.fsh = c->sh(); }
         rows.push_back(r);
     }
     for (auto &ft : first_touch) {
         const Cell *c = peek(ft.first);
-        rows.push_back(MemInitRow{ft.first, ft.second, c->val, c->ts, c->sh, 0});
+        rows.push_back(MemInitRow{ft.first, ft.second, c->val, c->ts(), c->sh(), 0});
     }
     std::sort(rows.begin(), rows.end(), [](const MemInitRow &x, const MemInitRow &y) { return x.addr < y.addr; });
     return rows;

@@ -210,6 +210,10 @@ int dvt_rv32_debug_device_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *job, 
  * (1..1024 queries, at most 30 bits; anything else is DVT_ERR_INPUT). */
 int dvt_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, size_t proof_len, uint32_t fri_queries,
                uint32_t pow_bits, int32_t *exit_code, uint8_t **public_values, size_t *pv_len, char **reason);
+/* measurement hook, host only: guest cycles per second of the executor alone; trace = 0: fast mode (the sequential
+ * pass of the prove pipeline), 1: trace mode (48-byte record per cycle).  0.0 when the guest does not halt. */
+double dvt_debug_exec_rate(const uint8_t *elf, size_t elf_len, const dvt_buf *stdin_bufs, size_t nbuf, uint32_t log_shard,
+                           int trace);
 /* test hook, host only: FP64 formulation of Poseidon2 (csrc/poseidon2_f64.cuh, what the hashing kernels run)
  * against the integer permutation on n states; returns the number of differing words (0 = identical) */
 uint64_t dvt_debug_p2_f64_selfcheck(uint32_t n, uint32_t seed);

@@ -1,0 +1,725 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY (imported by tests/ alone; never by the product path).
+
+An independent restatement, in plain Python, of the two pieces of the path that the C oracle does not cover:
+  * the guest machine: ELF32 loader, RV32IM decoder and interpreter with SP1's syscall ABI
+    (what stands behind reference src/main.rs:439-442 `client.execute(elf,&stdin).run()`), and
+  * K0, the expansion of an execution into the per-chip trace matrices of the rv32 machine
+    (SURVEY.md section 8(a) row K0), written from the AIR's own description (tools/airgen/rv32.py: which witness a
+    constraint names) and DESIGN.md section 5 — NOT from the product's csrc/rv32.h / rv32_exec.hip, which it is used to
+    check: tests compare the product's host expansion AND the device kernel's output with these matrices cell by
+    cell, and feed the oracle CPU prover from them.
+
+Only column NAMES are taken from the AIR description (tools.airgen.rv32.build()); every value is computed here.
+Slow by design (pure Python): use on guests of at most ~10^5 cycles.
+"""
+import struct
+
+import numpy as np
+
+P = 2013265921
+M32 = 0xFFFFFFFF
+ADDR_LIMIT = 0x38000000
+B_AND, B_OR, B_XOR, B_LTU, B_MSB, B_RANGE, B_U16 = 1, 2, 3, 4, 5, 6, 7
+ALU_CODES = dict(sll=1, srl=2, sra=3, mulh=4, mulhsu=5, div=6, divu=7, rem=8, remu=9)
+
+
+def sx(v, bits=32):
+    return v - (1 << bits) if v >> (bits - 1) else v
+
+
+def inv(x):
+    return pow(x % P, P - 2, P)
+
+
+# ---------------------------------------------------------------------------------------------- decoding
+class Ins:
+    __slots__ = ("pc", "word", "kind", "rd", "rs1", "rs2", "imm", "off", "tgt", "alu", "imm_form", "ok")
+
+    def __init__(self, pc, word):
+        self.pc, self.word, self.kind, self.rd, self.rs1, self.rs2 = pc, word, None, 0, 0, 0
+        self.imm = self.off = self.tgt = self.alu = 0
+        self.imm_form, self.ok = False, True
+
+
+def decode(word, pc):
+    """kind in: lui (also auipc, constant folded), jal, jalr, beq.., lb lbu lh lhu lw, sb sh sw, add sub and or xor slt
+    sltu mul mulhu, alu (shifts, mulh/mulhsu/div/divu/rem/remu -> other chips), ecall; ok = False: no chip"""
+    i = Ins(pc, word)
+    op, rd, f3, rs1, rs2, f7 = word & 0x7F, (word >> 7) & 31, (word >> 12) & 7, (word >> 15) & 31, (word >> 20) & 31, word >> 25
+    imm_i = sx(word >> 20, 12) & M32
+    imm_s = sx(((word >> 25) << 5) | ((word >> 7) & 31), 12) & M32
+    imm_b = sx((((word >> 31) & 1) << 12) | (((word >> 7) & 1) << 11) | (((word >> 25) & 63) << 5) | (((word >> 8) & 15) << 1), 13) & M32
+    imm_j = sx((((word >> 31) & 1) << 20) | (((word >> 12) & 255) << 12) | (((word >> 20) & 1) << 11) | (((word >> 21) & 1023) << 1), 21) & M32
+    if op == 0x37:
+        i.kind, i.rd, i.imm = "lui", rd, word & 0xFFFFF000
+    elif op == 0x17:
+        i.kind, i.rd, i.imm = "lui", rd, (pc + (word & 0xFFFFF000)) & M32
+    elif op == 0x6F:
+        i.kind, i.rd, i.imm, i.tgt = "jal", rd, (pc + 4) & M32, (pc + imm_j) & M32
+    elif op == 0x67 and f3 == 0:
+        i.kind, i.rd, i.rs1, i.imm, i.off = "jalr", rd, rs1, (pc + 4) & M32, imm_i
+    elif op == 0x63 and f3 in (0, 1, 4, 5, 6, 7):
+        i.kind = {0: "beq", 1: "bne", 4: "blt", 5: "bge", 6: "bltu", 7: "bgeu"}[f3]
+        i.rs1, i.rs2, i.tgt = rs1, rs2, (pc + imm_b) & M32
+    elif op == 0x03 and f3 in (0, 1, 2, 4, 5):
+        i.kind, i.rd, i.rs1, i.off = {0: "lb", 1: "lh", 2: "lw", 4: "lbu", 5: "lhu"}[f3], rd, rs1, imm_i
+    elif op == 0x23 and f3 in (0, 1, 2):
+        i.kind, i.rs1, i.rs2, i.off = {0: "sb", 1: "sh", 2: "sw"}[f3], rs1, rs2, imm_s
+    elif op == 0x13:
+        i.rd, i.rs1, i.imm_form = rd, rs1, True
+        if f3 in (0, 2, 3, 4, 6, 7):
+            i.kind, i.imm = {0: "add", 2: "slt", 3: "sltu", 4: "xor", 6: "or", 7: "and"}[f3], imm_i
+        elif f3 == 1 and f7 == 0:
+            i.kind, i.alu, i.imm = "alu", "sll", rs2
+        elif f3 == 5 and f7 in (0, 0x20):
+            i.kind, i.alu, i.imm = "alu", "srl" if f7 == 0 else "sra", rs2
+        else:
+            i.ok = False
+    elif op == 0x33:
+        i.rd, i.rs1, i.rs2 = rd, rs1, rs2
+        table = {(0, 0): "add", (0x20, 0): "sub", (0, 2): "slt", (0, 3): "sltu", (0, 4): "xor", (0, 6): "or", (0, 7): "and",
+                 (1, 0): "mul", (1, 3): "mulhu"}
+        alus = {(0, 1): "sll", (0, 5): "srl", (0x20, 5): "sra", (1, 1): "mulh", (1, 2): "mulhsu", (1, 4): "div", (1, 5): "divu",
+                (1, 6): "rem", (1, 7): "remu"}
+        if (f7, f3) in table:
+            i.kind = table[(f7, f3)]
+        elif (f7, f3) in alus:
+            i.kind, i.alu = "alu", alus[(f7, f3)]
+        else:
+            i.ok = False
+    elif word == 0x73:
+        i.kind, i.rd, i.rs1, i.rs2 = "ecall", 5, 5, 10
+    else:
+        i.ok = False
+    return i
+
+
+def alu_result(name, b, c):
+    s = c & 31
+    if name == "sll":
+        return (b << s) & M32
+    if name == "srl":
+        return b >> s
+    if name == "sra":
+        return (sx(b) >> s) & M32
+    if name == "mulh":
+        return ((sx(b) * sx(c)) >> 32) & M32
+    if name == "mulhsu":
+        return ((sx(b) * c) >> 32) & M32
+    if name == "divu":
+        return M32 if c == 0 else b // c
+    if name == "remu":
+        return b if c == 0 else b % c
+    if c == 0:
+        return M32 if name == "div" else b
+    if b == 0x80000000 and c == M32:
+        return b if name == "div" else 0
+    q = abs(sx(b)) // abs(sx(c))
+    if (sx(b) < 0) != (sx(c) < 0):
+        q = -q
+    return (q if name == "div" else sx(b) - q * sx(c)) & M32
+
+
+# ---------------------------------------------------------------------------------------------- the machine
+class Trap(Exception):
+    pass
+
+
+class Row:
+    """one retired instruction with everything the cpu chip's row needs"""
+    __slots__ = ("ins", "a", "b", "c", "next_pc", "pa", "pb", "pc_", "mem", "maddr", "m_prev", "m_val")
+
+
+class Run:
+    def __init__(self, elf: bytes, stdin=(), log_shard=21, max_cycles=1 << 32):
+        self.log_shard = log_shard
+        self._load(elf)
+        self.stdin = [bytes(b) for b in stdin]
+        self.next_input = 0
+        self.public_values, self.stdout = b"", b""
+        self.committed = {}
+        self.exit_code, self.halted, self.error, self.cycles = -1, False, "", 0
+        self.unsupported = False
+        # state: value and (shard, clk) of the last access per register / memory word
+        self.reg = [0] * 32
+        self.reg_t = [(0, 0)] * 32
+        self.mem = dict(self.image_mem)         # addr -> value
+        self.mem_t = {}                         # addr -> (shard, clk) of the last access
+        self.first_val = {}                     # non-image words: value at their first access
+        self.hinted = set()
+        self.shards = []
+        try:
+            self._run(max_cycles)
+        except Trap as e:
+            self.error = str(e)
+
+    # ---- ELF
+    def _load(self, elf):
+        if len(elf) < 52 or elf[:4] != b"\x7fELF" or elf[4] != 1 or elf[5] != 1:
+            raise ValueError("not an ELF32 little-endian file")
+        (machine,) = struct.unpack_from("<H", elf, 18)
+        if machine != 243:
+            raise ValueError("not RISC-V")
+        self.entry, phoff = struct.unpack_from("<II", elf, 24)
+        phentsize, phnum = struct.unpack_from("<HH", elf, 42)
+        self.image_mem, self.text = {}, {}
+        self.text_base = None
+        for k in range(phnum):
+            typ, off, vaddr, _, filesz, memsz, flags, _ = struct.unpack_from("<8I", elf, phoff + k * phentsize)
+            if typ != 1:
+                continue
+            blob = elf[off:off + filesz] + b"\0" * (memsz - filesz)
+            blob += b"\0" * (-len(blob) % 4)
+            for j in range(0, memsz, 4):
+                self.image_mem[vaddr + j] = struct.unpack_from("<I", blob, j)[0]
+            if flags & 1:
+                self.text_base = vaddr
+                self.n_instr = (filesz + 3) // 4
+                for j in range(self.n_instr):
+                    self.text[vaddr + 4 * j] = decode(self.image_mem[vaddr + 4 * j], vaddr + 4 * j)
+        # the program table lists the instructions that have a chip, in address order
+        self.provable = [i for _, i in sorted(self.text.items()) if i.ok]
+
+    # ---- memory argument bookkeeping
+    def _touch_reg(self, r, t):
+        prev = self.reg_t[r]
+        self.reg_t[r] = t
+        return prev
+
+    def _mem_word(self, addr):
+        if addr not in self.mem:
+            self.mem[addr] = 0
+        if addr not in self.image_mem and addr not in self.first_val:
+            self.first_val[addr] = self.mem[addr]
+        return self.mem[addr]
+
+    def _run(self, max_cycles):
+        pc, shard, i_in = self.entry, 1, 0
+        size = 1 << self.log_shard
+        cur = dict(index=1, start_pc=pc, rows=[], alu=[])
+        while True:
+            if self.cycles >= max_cycles:
+                raise Trap("cycle limit reached before HALT")
+            if i_in == size:
+                cur["next_pc"] = pc
+                self.shards.append(cur)
+                shard, i_in = shard + 1, 0
+                cur = dict(index=shard, start_pc=pc, rows=[], alu=[])
+            ins = self.text.get(pc)
+            if ins is None:
+                raise Trap("pc outside text at pc 0x%x" % pc)
+            clk = 4 * (i_in + 1)
+            if not ins.ok:
+                if ins.word & 0x7F != 0x0F:
+                    raise Trap("illegal instruction at pc 0x%x" % pc)
+                self.unsupported = True
+                pc, i_in, self.cycles = pc + 4, i_in + 1, self.cycles + 1
+                continue
+            row = Row()
+            row.ins, row.pa, row.pb, row.pc_, row.mem = ins, None, None, None, None
+            k = ins.kind
+            # ports in time order: rs2 at clk, rs1 at clk + 1, memory at clk + 2, rd at clk + 3
+            reads_rs2 = (k in ("beq", "bne", "blt", "bge", "bltu", "bgeu", "sb", "sh", "sw", "ecall")
+                         or (not ins.imm_form and k in ("add", "sub", "and", "or", "xor", "slt", "sltu", "mul", "mulhu", "alu")))
+            reads_rs1 = k not in ("lui", "jal")
+            b = c = a = 0
+            if reads_rs2:
+                c = self.reg[ins.rs2]
+                row.pc_ = self._touch_reg(ins.rs2, (shard, clk))
+            if ins.imm_form:
+                c = ins.imm
+            if reads_rs1:
+                b = self.reg[ins.rs1]
+                row.pb = self._touch_reg(ins.rs1, (shard, clk + 1))
+            nxt = (pc + 4) & M32
+            if k == "add":
+                a = (b + c) & M32
+            elif k == "sub":
+                a = (b - c) & M32
+            elif k == "and":
+                a = b & c
+            elif k == "or":
+                a = b | c
+            elif k == "xor":
+                a = b ^ c
+            elif k == "slt":
+                a = int(sx(b) < sx(c))
+            elif k == "sltu":
+                a = int(b < c)
+            elif k == "mul":
+                a = (b * c) & M32
+            elif k == "mulhu":
+                a = (b * c) >> 32
+            elif k == "lui":
+                a = ins.imm
+            elif k == "jal":
+                a, nxt = ins.imm, ins.tgt
+            elif k == "jalr":
+                t = (b + ins.off) & M32
+                if t >= ADDR_LIMIT:
+                    raise Trap("jump target out of range at pc 0x%x" % pc)
+                a, nxt = ins.imm, t & ~1
+            elif k in ("beq", "bne", "blt", "bge", "bltu", "bgeu"):
+                taken = {"beq": b == c, "bne": b != c, "blt": sx(b) < sx(c), "bge": sx(b) >= sx(c), "bltu": b < c, "bgeu": b >= c}[k]
+                if taken:
+                    nxt = ins.tgt
+            elif k == "alu":
+                a = alu_result(ins.alu, b, c)
+                cur["alu"].append((ins.alu, a, b, c))
+            elif k in ("lb", "lbu", "lh", "lhu", "lw", "sb", "sh", "sw"):
+                addr = (b + ins.off) & M32
+                if addr < 32 or addr >= ADDR_LIMIT:
+                    raise Trap("memory access out of range at pc 0x%x" % pc)
+                if (k in ("lw", "sw") and addr & 3) or (k in ("lh", "lhu", "sh") and addr & 1):
+                    raise Trap("misaligned %s access at pc 0x%x" % ("word" if k in ("lw", "sw") else "halfword", pc))
+                wa, sh8 = addr & ~3, 8 * (addr & 3)
+                before = self._mem_word(wa)
+                after = before
+                if k == "lw":
+                    a = before
+                elif k == "lb":
+                    a = sx((before >> sh8) & 0xFF, 8) & M32
+                elif k == "lbu":
+                    a = (before >> sh8) & 0xFF
+                elif k == "lh":
+                    a = sx((before >> sh8) & 0xFFFF, 16) & M32
+                elif k == "lhu":
+                    a = (before >> sh8) & 0xFFFF
+                elif k == "sw":
+                    after = c
+                elif k == "sb":
+                    after = (before & ~(0xFF << sh8) & M32) | ((c & 0xFF) << sh8)
+                else:
+                    after = (before & ~(0xFFFF << sh8) & M32) | ((c & 0xFFFF) << sh8)
+                self.mem[wa] = after
+                row.mem = self.mem_t.get(wa, (0, 0))
+                self.mem_t[wa] = (shard, clk + 2)
+                row.maddr, row.m_prev, row.m_val = addr, before, after
+            elif k == "ecall":
+                a = b
+                a1, a2 = self.reg[11], self.reg[12]
+                if b == 0x00:
+                    self.halted, self.exit_code, nxt = True, sx(c), 0
+                elif b == 0x02:
+                    if a1 + a2 > ADDR_LIMIT:
+                        raise Trap("WRITE buffer out of range at pc 0x%x" % pc)
+                    data = bytes((self.mem.get((a1 + j) & ~3, 0) >> (8 * ((a1 + j) & 3))) & 0xFF if a1 + j >= 32 else 0 for j in range(a2))
+                    if c == 3:
+                        self.public_values += data
+                    else:
+                        self.stdout += data
+                elif b == 0x10:
+                    row.mem = self._touch_reg(11, (shard, clk + 2))
+                    row.maddr, row.m_prev, row.m_val = 11, a1, a1
+                    if c < 8:
+                        self.committed[c] = a1
+                elif b == 0x1A:
+                    pass
+                elif b == 0xF0:
+                    a = len(self.stdin[self.next_input]) if self.next_input < len(self.stdin) else 0
+                elif b == 0xF1:
+                    if self.next_input >= len(self.stdin):
+                        raise Trap("HINT_READ with no input left at pc 0x%x" % pc)
+                    buf = self.stdin[self.next_input]
+                    self.next_input += 1
+                    if a1 != len(buf):
+                        raise Trap("HINT_READ length mismatch at pc 0x%x" % pc)
+                    if c % 4 or c < 32 or c + a1 > ADDR_LIMIT:
+                        raise Trap("HINT_READ pointer misaligned or out of range at pc 0x%x" % pc)
+                    padded = buf + b"\0" * (-len(buf) % 4)
+                    for j in range(0, len(buf), 4):
+                        if (c + j) in self.image_mem or (c + j) in self.mem_t:
+                            raise Trap("HINT_READ into the program image or into memory that was already accessed at pc 0x%x" % pc)
+                        self.mem[c + j] = struct.unpack_from("<I", padded, j)[0]
+                else:
+                    raise Trap("unknown syscall at pc 0x%x" % pc)
+            else:
+                raise AssertionError(k)
+            if ins.rd != 0:
+                row.pa = (self.reg[ins.rd],) + self._touch_reg(ins.rd, (shard, clk + 3))
+                self.reg[ins.rd] = a
+            row.a, row.b, row.c, row.next_pc = a, b, c, nxt
+            cur["rows"].append(row)
+            pc, i_in, self.cycles = nxt, i_in + 1, self.cycles + 1
+            if self.halted:
+                cur["next_pc"] = 0
+                self.shards.append(cur)
+                return
+
+    # ---- the sorted initial / final table of the last shard
+    def mem_rows(self):
+        rows = []
+        for addr in range(32):
+            t = self.reg_t[addr]
+            rows.append((addr, 0, self.reg[addr] if t != (0, 0) else 0, t, 1))
+        for addr, v in self.image_mem.items():
+            t = self.mem_t.get(addr, (0, 0))
+            rows.append((addr, v, self.mem[addr] if t != (0, 0) else v, t, 1))
+        for addr, v in self.first_val.items():
+            rows.append((addr, v, self.mem[addr], self.mem_t[addr], 0))
+        rows.sort()
+        return rows
+
+
+# ---------------------------------------------------------------------------------------------- K0: trace matrices
+def _chips():
+    from tools.airgen import rv32
+
+    m = rv32.build()
+    return {c.name: (i, c) for i, c in enumerate(m.chips)}, rv32
+
+
+def byts(w):
+    return [(w >> (8 * i)) & 0xFF for i in range(4)]
+
+
+class Lookups:
+    def __init__(self):
+        self.byte = np.zeros((7, 65536), np.int64)
+
+    def add(self, op, b, c=0):
+        self.byte[op - 1, (b << 8) | c if op != B_U16 else b] += 1
+
+
+def _col_setter(chip, mat, row):
+    idx = {n: i for i, n in enumerate(chip.main_names)}
+
+    def put(name, v):
+        mat[idx[name], row] = v % P
+
+    def putv(name, vals):
+        for i, v in enumerate(vals):
+            mat[idx[f"{name}[{i}]"], row] = v % P
+
+    return put, putv
+
+
+def log2ceil(n):
+    l = 0
+    while (1 << l) < n:
+        l += 1
+    return l
+
+
+def traces(run: Run, pos: int):
+    """-> (list of dict(chip_id, log_n, main [w][N], prep [w][N]) sorted by chip id, public values) for shard `pos`"""
+    chips, air = _chips()
+    sh = run.shards[pos]
+    shard = sh["index"]
+    last = pos + 1 == len(run.shards)
+    lk = Lookups()
+    prog_mult = {}
+    out = {}
+    FLAGS = air.FLAGS
+
+    def gap(prev, now_clk):
+        """(same-shard flag, 16-bit low limb, 8-bit high limb) of the timestamp gap to the previous access"""
+        psh, pclk = prev
+        d = now_clk - pclk - 1 if psh == shard else shard - psh - 1
+        assert 0 <= d < 1 << 24
+        return int(psh == shard), d & 0xFFFF, d >> 16
+
+    # ---- cpu
+    cid, chip = chips["cpu"]
+    n = 1 << log2ceil(len(sh["rows"]))
+    cpu = np.zeros((chip.main_width, n), np.int64)
+    fam_of = dict(add="is_add", sub="is_sub", slt="is_slt", sltu="is_sltu", mul="is_mul", mulhu="is_mulhu", lui="is_lui", jal="is_jal", jalr="is_jalr",
+                  beq="is_beq", bne="is_bne", blt="is_blt", bge="is_bge", bltu="is_bltu", bgeu="is_bgeu", lw="is_lw", sw="is_sw", ecall="is_ecall",
+                  lb="is_lb", lbu="is_lbu", lh="is_lh", lhu="is_lhu", sb="is_sb", sh="is_sh", alu="is_alu")
+    fam_of.update({"and": "is_and", "or": "is_or", "xor": "is_xor"})
+    for r, row in enumerate(sh["rows"]):
+        ins, a, b, c = row.ins, row.a, row.b, row.c
+        put, putv = _col_setter(chip, cpu, r)
+        clk = 4 * (r + 1)
+        k = ins.kind
+        put("clk", clk); put("pc", ins.pc); put("next_pc", row.next_pc)
+        put("rd", ins.rd); put("rs1", ins.rs1); put("rs2", ins.rs2)
+        putv("imm", byts(ins.imm)); putv("off", byts(ins.off))
+        put("aux", ins.tgt + (ALU_CODES[ins.alu] if k == "alu" else 0))
+        putv("a", byts(a)); putv("b", byts(b)); putv("c", byts(c))
+        put(fam_of[k], 1)
+        put("rd_en", int(ins.rd != 0)); put("imm_c", int(ins.imm_form))
+        prog_mult[ins.pc] = prog_mult.get(ins.pc, 0) + 1
+        hi = dict(pa=0, pb=0, pc=0, m=0)
+        for port, prev, t in (("pc", row.pc_, clk), ("pb", row.pb, clk + 1)):
+            if prev is not None:
+                same, lo, h = gap(prev, t)
+                put(f"{port}_ts", prev[1]); put(f"{port}_sh", prev[0]); put(f"{port}_same", same); put(f"{port}_lo", lo)
+                hi[port] = h
+                lk.add(B_U16, lo)
+        if row.pa is not None:
+            same, lo, h = gap(row.pa[1:], clk + 3)
+            putv("pa_prev", byts(row.pa[0]))
+            put("pa_ts", row.pa[2]); put("pa_sh", row.pa[1]); put("pa_same", same); put("pa_lo", lo)
+            hi["pa"] = h
+            lk.add(B_U16, lo)
+        U = [0] * air.UNION_W
+
+        def mem_port(prev_val, new_val, prev_t):
+            same, lo, h = gap(prev_t, clk + 2)
+            U[9:13], U[13:17] = byts(new_val), byts(prev_val)
+            U[17], U[8], U[18], U[19], U[20] = prev_t[1], lo, h, prev_t[0], same
+            hi["m"] = h
+            lk.add(B_U16, lo)
+
+        if k in ("add", "sub"):
+            x, cy = (b if k == "add" else a), 0
+            for i in range(4):
+                cy = (byts(x)[i] + byts(c)[i] + cy) >> 8
+                U[i] = cy
+        elif k in ("and", "or", "xor"):
+            for i in range(4):
+                U[11 + i], U[4 + i], U[19 + i] = byts(a)[i], byts(b)[i], byts(c)[i]
+                lk.add({"and": B_AND, "or": B_OR, "xor": B_XOR}[k], byts(b)[i], byts(c)[i])
+        elif k in ("slt", "sltu", "beq", "bne", "blt", "bge", "bltu", "bgeu"):
+            signed = k in ("slt", "blt", "bge")
+            bb, cc = byts(b), byts(c)
+            if signed:
+                U[24], U[25], U[9], U[21] = bb[3], bb[3] >> 7, cc[3], cc[3] >> 7
+                lk.add(B_MSB, bb[3]); lk.add(B_MSB, cc[3])
+                bb[3] ^= 0x80; cc[3] ^= 0x80
+            top = next((i for i in (3, 2, 1, 0) if bb[i] != cc[i]), None)
+            bc, ccv = (bb[top], cc[top]) if top is not None else (0, 0)
+            if top is not None:
+                U[top] = 1
+                U[4] = inv(bc - ccv)
+            U[10], U[20], U[19] = bc, ccv, int(bc < ccv)
+            lk.add(B_LTU, bc, ccv)
+        elif k in ("mul", "mulhu"):
+            prod = b * c
+            pb8 = [(prod >> (8 * i)) & 0xFF for i in range(8)]
+            carries, acc = [], 0
+            for kk in range(8):
+                acc += sum(byts(b)[i] * byts(c)[kk - i] for i in range(4) if 0 <= kk - i < 4)
+                assert acc & 0xFF == pb8[kk]
+                acc >>= 8
+                carries.append(acc)
+            other = pb8[4:] if k == "mul" else pb8[:4]
+            U[0:4] = other
+            U[4:11] = carries[:7]
+            for v in carries[:7]:
+                lk.add(B_U16, v)
+            lk.add(B_RANGE, other[0], other[1]); lk.add(B_RANGE, other[2], other[3])
+        elif k in ("lw", "sw", "lb", "lbu", "lh", "lhu", "sb", "sh", "jalr"):
+            total, cy = (b + ins.off) & M32, 0
+            for i in range(4):
+                t = byts(b)[i] + byts(ins.off)[i] + cy
+                U[i], cy = t & 0xFF, t >> 8
+                U[4 + i] = cy
+            s = byts(total)
+            lk.add(B_RANGE, s[0], s[1]); lk.add(B_RANGE, s[2], s[3]); lk.add(B_LTU, s[3], ADDR_LIMIT >> 24)
+            if k == "jalr":
+                U[8] = total & 1
+            else:
+                mem_port(row.m_prev, row.m_val, row.mem)
+                lk.add(B_AND, s[0], 3)
+                o = total & 3
+                if o:
+                    U[20 + o] = 1
+                if k in ("lb", "lh"):
+                    sb = byts(a)[0] if k == "lb" else byts(a)[1]
+                    U[24], U[25] = sb, sb >> 7
+                    lk.add(B_MSB, sb)
+        elif k == "ecall":
+            sid = b % P
+            U[4] = int(sid == 0)
+            U[5] = inv(sid) if sid else 0
+            is_commit = int(sid == 0x10)
+            U[6] = is_commit
+            U[7] = 0 if is_commit else inv(sid - 0x10)
+            put("commit_m", is_commit)
+            if is_commit:
+                U[0] = 11
+                mem_port(row.m_prev, row.m_val, row.mem)
+        putv("u", U)
+        put("pb_hi", hi["pb"]); put("pc_hi", hi["pc"]); put("pa_hi", hi["pa"])
+        lk.add(B_RANGE, hi["pb"], hi["pc"]); lk.add(B_RANGE, hi["pa"], hi["m"])
+        if k in ("add", "sub", "mul", "mulhu", "ecall"):
+            lk.add(B_RANGE, byts(a)[0], byts(a)[1]); lk.add(B_RANGE, byts(a)[2], byts(a)[3])
+    out["cpu"] = cpu
+
+    # ---- shift
+    ev = [e for e in sh["alu"] if e[0] in ("sll", "srl", "sra")]
+    if ev:
+        cid, chip = chips["shift"]
+        mat = np.zeros((chip.main_width, 1 << log2ceil(len(ev))), np.int64)
+        for r, (name, a, b, c) in enumerate(ev):
+            put, putv = _col_setter(chip, mat, r)
+            s5 = c & 31
+            q, rb = s5 >> 3, s5 & 7
+            m, mi = 1 << rb, 1 << (8 - rb)
+            left = name == "sll"
+            sgn = (b >> 31) if name == "sra" else 0
+            put("is_real", 1); put("is_" + name, 1); put("sh", s5); put("sgn", sgn)
+            qv = [0, 0, 0]
+            if q:
+                qv[q - 1] = 1
+            putv("q", qv)
+            putv("r", [int(i == rb) for i in range(8)])
+            putv("a", byts(a)); putv("b", byts(b)); putv("c", byts(c))
+            lo, hi4 = [], []
+            for i in range(4):
+                if left:
+                    pr = byts(b)[i] * m
+                    lo.append(pr & 0xFF); hi4.append(pr >> 8)
+                else:
+                    hi4.append(byts(b)[i] >> rb); lo.append(byts(b)[i] & (m - 1))
+            t = [(lo[i] + (hi4[i - 1] if i else 0)) if left else (hi4[i] + (lo[i + 1] * mi if i < 3 else sgn * (256 - mi))) for i in range(4)]
+            putv("lo", lo); putv("hi", hi4); putv("t", t)
+            lk.add(B_AND, byts(c)[0], 31)
+            lk.add(B_RANGE, lo[0], lo[1]); lk.add(B_RANGE, lo[2], lo[3]); lk.add(B_RANGE, hi4[0], hi4[1]); lk.add(B_RANGE, hi4[2], hi4[3])
+            if name == "sra":
+                lk.add(B_MSB, byts(b)[3])
+            if not left:
+                for i in range(4):
+                    lk.add(B_LTU, lo[i], m)
+        out["shift"] = mat
+
+    # ---- muldiv
+    ev = [e for e in sh["alu"] if e[0] not in ("sll", "srl", "sra")]
+    if ev:
+        cid, chip = chips["muldiv"]
+        mat = np.zeros((chip.main_width, 1 << log2ceil(len(ev))), np.int64)
+        for r, (name, a, b, c) in enumerate(ev):
+            put, putv = _col_setter(chip, mat, r)
+            is_mul, is_sdr = name in ("mulh", "mulhsu"), name in ("div", "rem")
+            is_dr = not is_mul
+            c0, ovf = is_dr and c == 0, is_sdr and b == 0x80000000 and c == M32
+            if is_mul:
+                q, rem = b, 0
+            elif c0:
+                q, rem = M32, b
+            elif ovf:
+                q, rem = b, 0
+            elif is_sdr:
+                q, rem = alu_result("div", b, c), alu_result("rem", b, c)
+            else:
+                q, rem = b // c, b % c
+            mx, my, mr, mb = q >> 31, c >> 31, rem >> 31, b >> 31
+            sxx = mx if (is_mul or is_sdr) else 0
+            syy = my if (name == "mulh" or is_sdr) else 0
+            srr, sbb = (mr, mb) if is_sdr else (0, 0)
+            put("is_real", 1); put("is_" + name, 1)
+            putv("a", byts(a)); putv("b", byts(b)); putv("c", byts(c)); putv("q", byts(q)); putv("r", byts(rem))
+            for nm, v in (("mx", mx), ("my", my), ("mr", mr), ("mb", mb), ("sx", sxx), ("sy", syy), ("sr", srr), ("sb", sbb)):
+                put(nm, v)
+            for v in (q, c, rem, b):
+                lk.add(B_MSB, byts(v)[3])
+            prod = q * c
+            pb8 = [(prod >> (8 * i)) & 0xFF for i in range(8)]
+            carries, acc = [], 0
+            for kk in range(8):
+                acc += sum(byts(q)[i] * byts(c)[kk - i] for i in range(4) if 0 <= kk - i < 4)
+                acc >>= 8
+                carries.append(acc)
+                lk.add(B_U16, acc)
+            putv("prod", pb8); putv("mcy", carries)
+            for kk in range(4):
+                lk.add(B_RANGE, pb8[2 * kk], pb8[2 * kk + 1])
+            h, bw, borrow = [], [], 0
+            for i in range(4):
+                t = pb8[4 + i] - sxx * byts(c)[i] - syy * byts(q)[i] - borrow
+                borrow = 0
+                while t < 0:
+                    t += 256
+                    borrow += 1
+                h.append(t); bw.append(borrow)
+            putv("h", h); putv("bw", bw)
+            lk.add(B_RANGE, h[0], h[1]); lk.add(B_RANGE, h[2], h[3])
+            lk.add(B_RANGE, byts(q)[0], byts(q)[1]); lk.add(B_RANGE, byts(q)[2], byts(q)[3])
+            lk.add(B_RANGE, byts(rem)[0], byts(rem)[1]); lk.add(B_RANGE, byts(rem)[2], byts(rem)[3])
+            dl0 = dl1 = 0
+            ea = 1
+            eb = 0
+            if is_dr:
+                put("is_c0", int(c0)); put("is_ovf", int(ovf))
+                csum = sum(byts(c))
+                put("cinv", inv(csum) if csum else 0)
+                if not ovf:
+                    Pl = [pb8[0] | pb8[1] << 8, pb8[2] | pb8[3] << 8, h[0] | h[1] << 8, h[2] | h[3] << 8]
+                    Rl = [rem & 0xFFFF, rem >> 16, 65535 * srr, 65535 * srr]
+                    cy, dcy = 0, []
+                    for kk in range(4):
+                        cy = (Pl[kk] + Rl[kk] + cy) >> 16
+                        dcy.append(cy)
+                    putv("dcy", dcy)
+                if not c0:
+                    sc_, sr_ = 1 - 2 * syy, 1 - 2 * srr
+                    t0 = sc_ * (c & 0xFFFF) - sr_ * (rem & 0xFFFF) - 1
+                    e0 = -(t0 // 65536)
+                    dl0 = t0 + 65536 * e0
+                    dl1 = sc_ * (c >> 16) - sr_ * (rem >> 16) + 65536 * (syy - srr) - e0
+                    ea, eb = (e0 + 1) & 1, (e0 + 1) >> 1
+            put("ea", ea); put("eb", eb)
+            putv("dl", [dl0, dl1])
+            lk.add(B_U16, dl0); lk.add(B_U16, dl1)
+        out["muldiv"] = mat
+
+    # ---- mem_init (last shard only)
+    if last:
+        cid, chip = chips["mem_init"]
+        rows = run.mem_rows()
+        mat = np.zeros((chip.main_width, 1 << log2ceil(len(rows))), np.int64)
+        prev = None
+        for r, (addr, v, f, t, is_img) in enumerate(rows):
+            put, putv = _col_setter(chip, mat, r)
+            d = addr - prev - 1 if prev is not None else 0
+            putv("ab", byts(addr)); putv("v", byts(v)); putv("f", byts(f)); putv("d", byts(d))
+            put("fts", t[1]); put("fsh", t[0]); put("is_img", is_img); put("is_real", 1)
+            for w in (addr, d):
+                lk.add(B_RANGE, byts(w)[0], byts(w)[1]); lk.add(B_RANGE, byts(w)[2], byts(w)[3]); lk.add(B_LTU, byts(w)[3], ADDR_LIMIT >> 24)
+            if not is_img:
+                lk.add(B_RANGE, byts(v)[0], byts(v)[1]); lk.add(B_RANGE, byts(v)[2], byts(v)[3])
+            prev = addr
+        out["mem_init"] = mat
+
+    # ---- preprocessed chips and their multiplicity columns
+    cidp, chipp = chips["program"]
+    np_rows = 1 << log2ceil(max(len(run.provable), 1))
+    prep = np.zeros((chipp.prep_width, np_rows), np.int64)
+    pidx = {nm: i for i, nm in enumerate(chipp.prep_names)}
+    mult = np.zeros((1, np_rows), np.int64)
+    for r in range(np_rows):
+        ins = run.provable[r] if r < len(run.provable) else run.provable[0]
+        k = ins.kind
+        vals = dict(pc=ins.pc, rd=ins.rd, rs1=ins.rs1, rs2=ins.rs2, aux=ins.tgt + (ALU_CODES[ins.alu] if k == "alu" else 0))
+        for i in range(4):
+            vals[f"imm[{i}]"], vals[f"off[{i}]"] = byts(ins.imm)[i], byts(ins.off)[i]
+        reads_rs2 = (k in ("beq", "bne", "blt", "bge", "bltu", "bgeu", "sb", "sh", "sw", "ecall")
+                     or (not ins.imm_form and k in ("add", "sub", "and", "or", "xor", "slt", "sltu", "mul", "mulhu", "alu")))
+        fl = {f: 0 for f in FLAGS}
+        fl[fam_of[k]] = 1
+        fl["rd_en"], fl["rs1_en"], fl["rs2_en"], fl["imm_c"] = int(ins.rd != 0), int(k not in ("lui", "jal")), int(reads_rs2), int(ins.imm_form)
+        vals.update(fl)
+        for nm, v in vals.items():
+            prep[pidx[nm], r] = v
+        if r < len(run.provable):
+            mult[0, r] = prog_mult.get(ins.pc, 0)
+    out["program"] = (mult, prep)
+    cidb, chipb = chips["byte"]
+    bprep = np.zeros((chipb.prep_width, 65536), np.int64)
+    rr = np.arange(65536)
+    bb, cc = rr >> 8, rr & 255
+    for nm, v in (("b", bb), ("c", cc), ("and", bb & cc), ("or", bb | cc), ("xor", bb ^ cc), ("ltu", (bb < cc).astype(np.int64)), ("msb", bb >> 7)):
+        bprep[chipb.prep_names.index(nm)] = v
+    out["byte"] = (lk.byte, bprep)
+    cidi, chipi = chips["mem_image"]
+    img = sorted([(a_, 0) for a_ in range(32)] + list(run.image_mem.items()))
+    ni = 1 << log2ceil(len(img))
+    iprep = np.zeros((chipi.prep_width, ni), np.int64)
+    for r, (addr, v) in enumerate(img):
+        iprep[chipi.prep_names.index("addr"), r] = addr
+        for i in range(4):
+            iprep[chipi.prep_names.index(f"v[{i}]"), r] = byts(v)[i]
+        iprep[chipi.prep_names.index("is_real"), r] = 1
+    out["mem_image"] = (np.zeros((1, ni), np.int64), iprep)
+
+    result = []
+    for name, (cid, chip) in sorted(chips.items(), key=lambda kv: kv[1][0]):
+        if name not in out:
+            continue
+        v = out[name]
+        main, prep_m = v if isinstance(v, tuple) else (v, np.zeros((0, v.shape[1]), np.int64))
+        result.append(dict(chip_id=cid, log_n=int(main.shape[1]).bit_length() - 1, main=(main % P).astype(np.uint32), prep=(prep_m % P).astype(np.uint32)))
+    pubs = np.array([sh["start_pc"] % P, sh["next_pc"] % P, (run.exit_code % P) if last else 0, shard, int(last)], np.uint32)
+    return result, pubs

@@ -1,6 +1,6 @@
-"""GPU parity test of K0 (trace expansion kernel): the traces generated on the device
-must equal, word for word, the host-side expansion — which tests/test_rv32_exec_trace.py
-validates against the oracle's constraint checker and exact LogUp multiset."""
+"""GPU parity test of K0 (trace expansion kernel): the traces generated on the device must equal, word for word,
+(a) the oracle's independent Python restatement of the guest machine and of the row expansion (oracle/rv32_model.py,
+written from the AIR description, not from the product's sources) and (b) the product's own host-side expansion."""
 import struct
 
 import numpy as np
@@ -26,14 +26,25 @@ def test_k0_device_traces_equal_host_traces(which, log_shard):
         elf = guests.bignum(5, limbs=6)[0]
     else:
         elf, stdin = guests.hint_sum(), [struct.pack("<5I", 9, 8, 7, 6, 5)]
+    from oracle import rv32_model
+
     p = capi.Prover('{"fri_queries": 8, "pow_bits": 4, "log_shard_size": %d}' % log_shard)
     pk, _ = p.setup(elf)
-    job, _ = p.prepare(pk, stdin)
+    job, rep = p.prepare(pk, stdin)
     n = p.job_shards(job)
+    run = rv32_model.Run(elf, stdin, log_shard)
+    assert n == len(run.shards) and rep["cycles"] == run.cycles
     assert n == capi.rv32_debug_traces(elf, stdin, log_shard, 0)[2]
     for shard in range(n):
         host, hpubs, _ = capi.rv32_debug_traces(elf, stdin, log_shard, shard)
         dev, dpubs = p.debug_device_traces(pk, job, shard)
+        model, mpubs = rv32_model.traces(run, shard)
+        assert (dpubs == mpubs).all() and len(model) == len(dev)
+        for m, d in zip(model, dev):
+            assert m["chip_id"] == d["chip_id"] and m["log_n"] == d["log_n"]
+            diff = np.argwhere(m["main"] != d["main"])
+            detail = [(int(c), int(r), int(m["main"][c, r]), int(d["main"][c, r])) for c, r in diff[:12]]
+            assert diff.size == 0, f"shard {shard} chip {m['chip_id']}: {len(diff)} cells differ from the oracle model, first (col,row,model,dev): {detail}"
         assert (dpubs == hpubs).all() and len(host) == len(dev)
         for h, d in zip(host, dev):
             assert h["chip_id"] == d["chip_id"] and h["log_n"] == d["log_n"]

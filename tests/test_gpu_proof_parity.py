@@ -35,13 +35,13 @@ def split_container(proof: bytes):
 
 
 def oracle_prove_execution(elf, stdin, log_shard):
-    from dvt_circuits_amd import capi
+    """the oracle side end to end: the traces come from the oracle's own guest machine + row expansion
+    (oracle/rv32_model.py), not from the product's executor"""
+    from oracle import rv32_model
 
-    shards, i, n = [], 0, 1
-    while i < n:
-        chips, pubs, n = capi.rv32_debug_traces(elf, stdin, log_shard, i)   # host traces == device traces (test_gpu_k0_parity)
-        shards.append((chips, pubs))
-        i += 1
+    run = rv32_model.Run(elf, stdin, log_shard)
+    assert run.halted and not run.error
+    shards = [rv32_model.traces(run, i) for i in range(len(run.shards))]
     prep_root = _oracle_prover.prep_root_of(shards[0][0])
     headers = [_oracle_prover.main_root(chips) + [int(x) for x in pubs] for chips, pubs in shards]
     gc = _oracle_prover.global_challenges(prep_root, headers)
