@@ -59,10 +59,17 @@ hipError_t launch_perm_t(hipStream_t st, const PermArgs &a) {
     perm_rows_kernel<Air><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(a);
     return hipGetLastError();
 }
+template <class Air, int PART>
+void launch_quotient_parts(hipStream_t st, const QuotientArgs &a, unsigned blocks) {
+    // parts 0 .. N_PARTS - 1: the chip's own constraints; then N_LPARTS groups of its LogUp constraints (none without interactions)
+    constexpr int LAST = Air::N_PARTS + (Air::N_INTERACTIONS > 0 ? Air::N_LPARTS : 0) - 1;
+    quotient_kernel<Air, PART><<<blocks, 256, 0, st>>>(a);
+    if constexpr (PART < LAST) launch_quotient_parts<Air, PART + 1>(st, a, blocks);
+}
 template <class Air>
 hipError_t launch_quotient_t(hipStream_t st, const QuotientArgs &a) {
     size_t m = (size_t)2 << a.log_n;
-    quotient_kernel<Air><<<(unsigned)((m + 255) / 256), 256, 0, st>>>(a);
+    launch_quotient_parts<Air, 0>(st, a, (unsigned)((m + 255) / 256));
     return hipGetLastError();
 }
 template <class Air>

@@ -175,12 +175,23 @@ struct ConstraintFolder {
         fold(base + 2, (phi_l - cumsum) * sel_last);
     }
 
+    // PART < 0: everything (the host verifier).  0 <= PART < Air::N_PARTS: that group of the chip's own constraints;
+    // N_PARTS <= PART < N_PARTS + N_LPARTS: that group of LogUp batches (the last one also the running-sum constraints).
+    // The folded value is the sum over the parts.
+    template <int PART = -1>
     DVT_HD Fp4 run() {
         if constexpr (BASE)
             for (int k = 0; k < 4; k++) perm_alpha_c.c[k] = centred_from_mont(perm_alpha.c[k].v);
-        Air::constraints(*this);
-        Air::interactions(*this);
-        finish_logup();
+        if constexpr (PART < 0) {
+            Air::constraints(*this);
+            Air::interactions(*this);
+            finish_logup();
+        } else if constexpr (PART < Air::N_PARTS) {
+            Air::template constraints_part<PART>(*this);
+        } else {
+            Air::template interactions_part<PART - Air::N_PARTS>(*this);
+            if constexpr (PART == Air::N_PARTS + Air::N_LPARTS - 1) finish_logup();
+        }
         if constexpr (BASE) {
             acc += acc_d.value();
             Fp4 lc;   // acc_c holds canonical residues: back to Montgomery words
@@ -280,7 +291,8 @@ struct QuotAccess {
     }
 };
 
-template <class Air>
+// One launch per part (ConstraintFolder::run<PART>): part 0 writes the quotient values, the later parts add to them.
+template <class Air, int PART>
 __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
     const size_t m = (size_t)2 << a.log_n;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -304,11 +316,14 @@ __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
     f.sel_first = zh * (pinv * d2);
     f.sel_last = zh * (pinv * d1);
     f.sel_trans = d2;
-    Fp4 q = f.run() * zhinv;
+    Fp4 q = f.template run<PART>() * zhinv;
     const size_t n = m >> 1;
     uint32_t *o = a.out + (odd ? 4 * n : 0) + (i >> 1);
 #pragma unroll
-    for (int k = 0; k < 4; k++) o[(size_t)k * n] = q.c[k].v;
+    for (int k = 0; k < 4; k++) {
+        if constexpr (PART == 0) o[(size_t)k * n] = q.c[k].v;
+        else o[(size_t)k * n] = (Fp::raw(o[(size_t)k * n]) + q.c[k]).v;
+    }
 }
 #endif  // __HIPCC__
 

@@ -343,6 +343,8 @@ def build_cpu():
     for i in range(4):
         ch.assert_zero(commit_m * (mv[i] - mp[i]))
     ch.send("pv", [word(c)] + mv, commit_m)
+    ch.quotient_parts = 4
+    ch.logup_parts = 5
     return ch
 
 
@@ -398,6 +400,7 @@ def build_shift():
         right = esum(qq[k] * (t[i + k] if i + k < 4 else fill) for k in range(4))
         ch.assert_zero(is_sll * (a[i] - left))
         ch.assert_zero(sel_r * (a[i] - right))
+    ch.quotient_parts = 2
     return ch
 
 
@@ -508,6 +511,8 @@ def build_muldiv():
     ch.assert_zero(sel_lt * (sc_ * (c[2] + 256 * c[3]) - sr_ * (r[2] + 256 * r[3]) + 65536 * (sy - sr) - e0 - dl[1]))
     ch.send("byte", [B_U16, 0, dl[0], 0], is_real)
     ch.send("byte", [B_U16, 0, dl[1], 0], is_real)
+    ch.quotient_parts = 2
+    ch.logup_parts = 2
     return ch
 
 
