@@ -3,12 +3,13 @@
 examples/finalization_test.json), for workloads larger than the reference's own example (SURVEY.md section 8d,
 configs 3-4).
 
-What is real: the structure, every field size, the commitment hashes base_hash = SHA-256(gen_id || n || k || len ||
-base_pubkeys...) (crates/dkg/src/verification.rs:151-175; tests/test_host_stdin.py pins this formula against the
-reference's example file) and the ordering of the generations by that hash.  What is NOT: the 48- / 96-byte "points"
-are pseudo-random bytes, not BLS12-381 elements (this image has no pairing library and the current-source guests that
-would check them cannot be built here), so the file exercises the host path and sizes the workload; a DKG-verifying
-guest would reject it.
+finalization(n, k, real_keys=True) runs a real (k, n) DKG over BLS12-381 (tools/bls12_381.py, pinned by the reference's
+KATs): n polynomials of k random scalars, base_pubkeys_i[j] = a_ij G1, commitment hashes, generations ordered by hash
+-> ids 1..n, partial keys S_i G1 with S_i = sum_j f_j(id_i), signatures S_i H(msg), aggregate sum_j a_j0 G1
+(SURVEY.md section 8d).  Such an input is accepted by the reference's finalization check (restated in
+tools/dkg_verify.py; tests/test_bls_tooling.py).  real_keys=False keeps the structure, sizes and commitment hashes
+(crates/dkg/src/verification.rs:151-175) but fills the 48- / 96-byte points with pseudo-random bytes: fast (no curve
+arithmetic), enough to size a workload for the synthetic guests, rejected by a DKG-verifying guest.
 
 Randomness: SHA-256 in counter mode over seed = 0xD17C0DE5 + n (sha256(seed_le64 || ctr_le64)), as SURVEY.md prescribes.
 
@@ -34,7 +35,40 @@ class Stream:
         return out
 
 
-def finalization(n, k, seed=None):
+def finalization_real(n, k, seed=None):
+    """a valid instance: see the module docstring"""
+    from tools import bls12_381 as B
+
+    assert 1 <= k <= n <= 255
+    B.ensure_ready()
+    rnd = Stream(0xD17C0DE5 + n if seed is None else seed)
+    gen_id = rnd.take(16)
+    polys = [[int.from_bytes(rnd.take(48), "big") % B.R for _ in range(k)] for _ in range(n)]
+    gens = []
+    for coeffs in polys:
+        pubkeys = [B.g1_compress(B.E1.mul(B.G1, a)) for a in coeffs]
+        h = hashlib.sha256(gen_id + bytes([n, k, len(pubkeys)]) + b"".join(pubkeys)).digest()
+        gens.append(dict(coeffs=coeffs, pubkeys=pubkeys, hash=h))
+    gens.sort(key=lambda g: g["hash"])
+    hm = B.hash_to_g2(MESSAGE.encode())
+    out = []
+    for i, g in enumerate(gens):
+        x = i + 1
+        share = sum(sum(a * pow(x, j, B.R) for j, a in enumerate(q["coeffs"])) for q in gens) % B.R      # S_i = sum_j f_j(id_i)
+        out.append({
+            "base_pubkeys": [p.hex() for p in g["pubkeys"]],
+            "base_hash": g["hash"].hex(),
+            "partial_pubkey": B.g1_compress(B.E1.mul(B.G1, share)).hex(),
+            "message_cleartext": MESSAGE,
+            "message_signature": B.g2_compress(B.E2.mul(hm, share)).hex(),
+        })
+    agg = B.E1.mul(B.G1, sum(g["coeffs"][0] for g in gens) % B.R)
+    return {"settings": {"n": n, "k": k, "gen_id": gen_id.hex()}, "generations": out, "aggregate_pubkey": B.g1_compress(agg).hex()}
+
+
+def finalization(n, k, seed=None, real_keys=False):
+    if real_keys:
+        return finalization_real(n, k, seed)
     assert 1 <= k <= n <= 255
     rnd = Stream(0xD17C0DE5 + n if seed is None else seed)
     gen_id = rnd.take(16)
@@ -80,6 +114,8 @@ if __name__ == "__main__":
     ap.add_argument("--k", type=int, default=2)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=None)
     ap.add_argument("--type", choices=("finalization", "bad-encrypted-share"), default="finalization")
+    ap.add_argument("--real-keys", action="store_true", help="finalization: a valid DKG instance over BLS12-381 (slow: pure-Python curve arithmetic)")
     a = ap.parse_args()
-    json.dump((finalization if a.type == "finalization" else bad_encrypted_share)(a.n, a.k, a.seed), sys.stdout, indent=1)
+    doc = finalization(a.n, a.k, a.seed, a.real_keys) if a.type == "finalization" else bad_encrypted_share(a.n, a.k, a.seed)
+    json.dump(doc, sys.stdout, indent=1)
     sys.stdout.write("\n")
