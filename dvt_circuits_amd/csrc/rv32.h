@@ -72,6 +72,35 @@ struct Program {
     std::vector<std::pair<uint32_t, uint32_t>> image;     // (byte address, word), sorted, word aligned
 };
 
+// The decode-time columns of an instruction as the AIR names them (tools/airgen/rv32.py FLAGS / VALUE_FLAGS): families
+// that differ only in a byte-table opcode or in signedness share a selector and carry that value beside it.
+struct ColFlags {
+    uint32_t rd_en, rs1_en, rs2_en, imm_c, is_add, is_sub, is_bit, is_set, is_mul, is_mulhu, is_lui, is_jal, is_jalr, is_beq, is_bne, is_brlt, is_brge,
+        is_lw, is_sw, is_ecall, is_lb, is_lbu, is_lh, is_lhu, is_sb, is_sh, is_alu, bit_op, cmp_signed, imm;
+};
+DVT_HD ColFlags column_flags(const Instr &in) {
+    const uint32_t fl = in.flags;
+    auto F = [&](uint32_t bit) -> uint32_t { return (fl >> bit) & 1u; };
+    ColFlags c;
+    c.rd_en = F(F_RD_EN); c.rs1_en = F(F_RS1_EN); c.rs2_en = F(F_RS2_EN); c.imm_c = F(F_IMM_C);
+    c.is_add = F(F_ADD); c.is_sub = F(F_SUB);
+    c.is_bit = F(F_AND) | F(F_OR) | F(F_XOR);
+    c.bit_op = F(F_AND) * B_AND + F(F_OR) * B_OR + F(F_XOR) * B_XOR;
+    c.is_set = F(F_SLT) | F(F_SLTU);
+    c.cmp_signed = F(F_SLT) | F(F_BLT) | F(F_BGE);
+    c.is_mul = F(F_MUL); c.is_mulhu = F(F_MULHU); c.is_lui = F(F_LUI); c.is_jal = F(F_JAL); c.is_jalr = F(F_JALR);
+    c.is_beq = F(F_BEQ); c.is_bne = F(F_BNE);
+    c.is_brlt = F(F_BLT) | F(F_BLTU);
+    c.is_brge = F(F_BGE) | F(F_BGEU);
+    c.is_lw = F(F_LW); c.is_sw = F(F_SW); c.is_ecall = F(F_ECALL);
+    c.is_lb = F(F_LB); c.is_lbu = F(F_LBU); c.is_lh = F(F_LH); c.is_lhu = F(F_LHU); c.is_sb = F(F_SB); c.is_sh = F(F_SH);
+    c.is_alu = F(F_ALU);
+    c.imm = in.imm | in.off;   // one immediate field: operand / LUI constant (imm) or address offset (off), never both
+    return c;
+}
+constexpr uint32_t LINK_TOP_BYTE = 0x78;   // tools/airgen/rv32.py: the top byte of a link value pc + 4 is below it
+constexpr uint32_t SYS_HINT_LEN = 0xF0;
+
 // One retired instruction, compact (what the host uploads for K0): 12 words = three 16-byte loads.
 // Timestamps are (shard, clk) pairs: *_ts = clk of the previous access of that port, its shard is a
 // 16-bit half of sh_ab / sh_cm.  Everything else of the row (next pc, memory word after a store, limbs,
@@ -219,19 +248,24 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
     s.put(RV32_CPU_rd, in.rd);
     s.put(RV32_CPU_rs1, in.rs1);
     s.put(RV32_CPU_rs2, in.rs2);
+    const ColFlags cf = column_flags(in);
     for (int i = 0; i < 4; i++) {
-        s.put(RV32_CPU_imm_0 + i, B(in.imm, i));
-        s.put(RV32_CPU_off_0 + i, B(in.off, i));
+        s.put(RV32_CPU_imm_0 + i, B(cf.imm, i));
         s.put(RV32_CPU_a_0 + i, B(r.a, i));
         s.put(RV32_CPU_b_0 + i, B(r.b, i));
         s.put(RV32_CPU_c_0 + i, B(r.c, i));
         s.put(RV32_CPU_pa_prev_0 + i, B(r.pa_prev, i));
     }
     s.put(RV32_CPU_aux, in.tgt + in.alu_op);   // target of the control-flow families / alu-bus opcode of F_ALU rows: never both
-    // flag columns: rd_en, imm_c, then the family flags in FLAGS order (rs1_en, rs2_en and is_real are linear in those)
-    s.put(RV32_CPU_rd_en, F(F_RD_EN));
-    s.put(RV32_CPU_imm_c, F(F_IMM_C));
-    for (uint32_t k = F_ADD; k < N_FLAGS; k++) s.put(RV32_CPU_is_add + (k - F_ADD), F(k));
+    // decode-time columns (rs1_en, rs2_en and is_real are linear in the family flags: no columns)
+    s.put(RV32_CPU_bit_op, cf.bit_op); s.put(RV32_CPU_cmp_signed, cf.cmp_signed);
+    s.put(RV32_CPU_rd_en, cf.rd_en); s.put(RV32_CPU_imm_c, cf.imm_c);
+    s.put(RV32_CPU_is_add, cf.is_add); s.put(RV32_CPU_is_sub, cf.is_sub); s.put(RV32_CPU_is_bit, cf.is_bit); s.put(RV32_CPU_is_set, cf.is_set);
+    s.put(RV32_CPU_is_mul, cf.is_mul); s.put(RV32_CPU_is_mulhu, cf.is_mulhu); s.put(RV32_CPU_is_lui, cf.is_lui); s.put(RV32_CPU_is_jal, cf.is_jal);
+    s.put(RV32_CPU_is_jalr, cf.is_jalr); s.put(RV32_CPU_is_beq, cf.is_beq); s.put(RV32_CPU_is_bne, cf.is_bne); s.put(RV32_CPU_is_brlt, cf.is_brlt);
+    s.put(RV32_CPU_is_brge, cf.is_brge); s.put(RV32_CPU_is_lw, cf.is_lw); s.put(RV32_CPU_is_sw, cf.is_sw); s.put(RV32_CPU_is_ecall, cf.is_ecall);
+    s.put(RV32_CPU_is_lb, cf.is_lb); s.put(RV32_CPU_is_lbu, cf.is_lbu); s.put(RV32_CPU_is_lh, cf.is_lh); s.put(RV32_CPU_is_lhu, cf.is_lhu);
+    s.put(RV32_CPU_is_sb, cf.is_sb); s.put(RV32_CPU_is_sh, cf.is_sh); s.put(RV32_CPU_is_alu, cf.is_alu);
     s.prog(r.idx);
     // register ports
     uint32_t pb_hi = 0, pc_hi = 0, pa_hi = 0, m_hi = 0;
@@ -340,6 +374,9 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
         s.byte(B_LTU - 1, (B(sum, 3) << 8) | (ADDR_LIMIT >> 24));
         if (F(F_JALR)) {
             s.put(U + 8, sum & 1);
+            // link value a = pc + 4: its top byte is below 0x78 (comparator slot: u[19] = 1 = "u[10] < u[20]")
+            s.put(U + 19, 1); s.put(U + 10, B(a, 3)); s.put(U + 20, LINK_TOP_BYTE);
+            s.byte(B_LTU - 1, (B(a, 3) << 8) | LINK_TOP_BYTE);
         } else {
             // the access moves the whole aligned word; stores patch it
             const uint32_t o = sum & 3, sh8 = 8 * o;
@@ -357,9 +394,15 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
                 s.byte(B_MSB - 1, sbyte << 8);
             }
         }
+    } else if (F(F_JAL)) {
+        s.put(U + 19, 1); s.put(U + 10, B(a, 3)); s.put(U + 20, LINK_TOP_BYTE);   // as for JALR: the link value's top byte
+        s.byte(B_LTU - 1, (B(a, 3) << 8) | LINK_TOP_BYTE);
     } else if (F(F_ECALL)) {
-        // u[4] is_halt, u[5] 1/id, u[6] is_commit, u[7] 1/(id - COMMIT); COMMIT rows read a1 (x11) through the memory port
+        // u[4] is_halt, u[5] 1/id, u[6] is_commit, u[7] 1/(id - COMMIT), u[24] is HINT_LEN (the one call that returns a value
+        // in t0), u[25] 1/(id - HINT_LEN); COMMIT rows read a1 (x11) through the memory port
         uint32_t idc = b % P;
+        s.put(U + 24, idc == SYS_HINT_LEN);
+        if (idc != SYS_HINT_LEN) s.put(U + 25, inv(Fp::from_canonical(idc) - Fp::from_canonical(SYS_HINT_LEN)).canonical());
         s.put(U + 4, idc == 0);
         if (idc) s.put(U + 5, inv(Fp::from_canonical(idc)).canonical());
         const bool is_commit = idc == SYS_COMMIT;
@@ -373,7 +416,7 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
     }
     s.byte(B_RANGE - 1, (pb_hi << 8) | pc_hi);
     s.byte(B_RANGE - 1, (pa_hi << 8) | m_hi);
-    if (F(F_ADD) | F(F_SUB) | F(F_MUL) | F(F_MULHU) | F(F_ECALL)) {
+    if (F(F_ADD) | F(F_SUB) | F(F_MUL) | F(F_MULHU) | F(F_ECALL) | F(F_JAL) | F(F_JALR)) {
         s.byte(B_RANGE - 1, (B(a, 0) << 8) | B(a, 1));
         s.byte(B_RANGE - 1, (B(a, 2) << 8) | B(a, 3));
     }

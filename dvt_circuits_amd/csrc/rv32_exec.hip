@@ -31,10 +31,10 @@ static Instr decode(uint32_t w, uint32_t pc) {
     switch (op) {
     case 0x37: set_rd(); in.imm = imm_u; in.flags |= FL(F_LUI); break;
     case 0x17: set_rd(); in.imm = pc + imm_u; in.flags |= FL(F_LUI); break;  // AUIPC folded at decode time
-    case 0x6f: set_rd(); in.imm = pc + 4; in.tgt = pc + imm_j; in.flags |= FL(F_JAL); break;
+    case 0x6f: set_rd(); in.tgt = pc + imm_j; in.flags |= FL(F_JAL); break;    // (the link value pc + 4 is constrained, not tabulated)
     case 0x67:
         if (f3 != 0) { in.supported = 0; break; }
-        set_rd(); set_rs1(); in.imm = pc + 4; in.off = imm_i; in.flags |= FL(F_JALR);
+        set_rd(); set_rs1(); in.off = imm_i; in.flags |= FL(F_JALR);
         break;
     case 0x63: {
         static const int map[8] = {F_BEQ, F_BNE, -1, -1, F_BLT, F_BGE, F_BLTU, F_BGEU};
@@ -320,10 +320,10 @@ L_XORI: RRI(b ^ c);
 L_SLTI: RRI((uint32_t)((int32_t)b < (int32_t)c));
 L_SLTIU: RRI((uint32_t)(b < c));
 L_LUI: BEGIN(); b = c = 0; a = IN.imm; PORT_A(a); SEQ();
-L_JAL: BEGIN(); b = c = 0; a = IN.imm; PORT_A(a); nip = code + IN.tgt_idx; NEXT();
+L_JAL: BEGIN(); b = c = 0; a = IN.pc + 4; PORT_A(a); nip = code + IN.tgt_idx; NEXT();
 L_JALR: {
     BEGIN(); c = 0; PORT_B();
-    a = IN.imm;
+    a = IN.pc + 4;
     const uint32_t t = b + IN.off;
     if (__builtin_expect(t >= ADDR_LIMIT, 0)) { why = "jump target out of range"; goto trapped; }
     const uint32_t tp = t & ~1u, ti = (tp - text_base) >> 2;
@@ -526,10 +526,18 @@ void build_prep(const Program &prog, HostPrep *out) {
     for (size_t r = 0; r < np; r++) {
         const Instr &in = *rows[r < rows.size() ? r : 0];
         auto put = [&](int col, uint32_t v) { P0[(size_t)col * np + r] = v; };
+        const ColFlags cf = column_flags(in);
         put(RV32_PROGRAM_P_pc, in.pc); put(RV32_PROGRAM_P_rd, in.rd); put(RV32_PROGRAM_P_rs1, in.rs1); put(RV32_PROGRAM_P_rs2, in.rs2);
-        for (int i = 0; i < 4; i++) { put(RV32_PROGRAM_P_imm_0 + i, (in.imm >> (8 * i)) & 0xff); put(RV32_PROGRAM_P_off_0 + i, (in.off >> (8 * i)) & 0xff); }
+        for (int i = 0; i < 4; i++) put(RV32_PROGRAM_P_imm_0 + i, (cf.imm >> (8 * i)) & 0xff);
         put(RV32_PROGRAM_P_aux, in.tgt + in.alu_op);
-        for (uint32_t k = 0; k < N_FLAGS; k++) put(RV32_PROGRAM_P_rd_en + k, (in.flags >> k) & 1);
+        put(RV32_PROGRAM_P_bit_op, cf.bit_op); put(RV32_PROGRAM_P_cmp_signed, cf.cmp_signed);
+        put(RV32_PROGRAM_P_rd_en, cf.rd_en); put(RV32_PROGRAM_P_rs1_en, cf.rs1_en); put(RV32_PROGRAM_P_rs2_en, cf.rs2_en); put(RV32_PROGRAM_P_imm_c, cf.imm_c);
+        put(RV32_PROGRAM_P_is_add, cf.is_add); put(RV32_PROGRAM_P_is_sub, cf.is_sub); put(RV32_PROGRAM_P_is_bit, cf.is_bit); put(RV32_PROGRAM_P_is_set, cf.is_set);
+        put(RV32_PROGRAM_P_is_mul, cf.is_mul); put(RV32_PROGRAM_P_is_mulhu, cf.is_mulhu); put(RV32_PROGRAM_P_is_lui, cf.is_lui); put(RV32_PROGRAM_P_is_jal, cf.is_jal);
+        put(RV32_PROGRAM_P_is_jalr, cf.is_jalr); put(RV32_PROGRAM_P_is_beq, cf.is_beq); put(RV32_PROGRAM_P_is_bne, cf.is_bne); put(RV32_PROGRAM_P_is_brlt, cf.is_brlt);
+        put(RV32_PROGRAM_P_is_brge, cf.is_brge); put(RV32_PROGRAM_P_is_lw, cf.is_lw); put(RV32_PROGRAM_P_is_sw, cf.is_sw); put(RV32_PROGRAM_P_is_ecall, cf.is_ecall);
+        put(RV32_PROGRAM_P_is_lb, cf.is_lb); put(RV32_PROGRAM_P_is_lbu, cf.is_lbu); put(RV32_PROGRAM_P_is_lh, cf.is_lh); put(RV32_PROGRAM_P_is_lhu, cf.is_lhu);
+        put(RV32_PROGRAM_P_is_sb, cf.is_sb); put(RV32_PROGRAM_P_is_sh, cf.is_sh); put(RV32_PROGRAM_P_is_alu, cf.is_alu);
     }
     // byte table
     H.log_n[RV32_CHIP_BYTE] = 16;

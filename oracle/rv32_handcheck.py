@@ -59,7 +59,7 @@ def check_lw(names, main, shard):
     u[13..16]) and equals a; the previous access (shard u[19], clk u[17]) is strictly earlier than (shard, clk + 2) with the
     gap in u[8] + 2^16 u[18]"""
     col, vec = _cols(names, main)
-    a, b, off, u = vec("a"), vec("b"), vec("off"), vec("u", 26)
+    a, b, off, u = vec("a"), vec("b"), vec("imm"), vec("u", 26)      # (the immediate field of a load is its address offset)
     rows = col("is_lw") == 1
     ok = np.ones_like(rows)
     carry = 0
@@ -109,11 +109,14 @@ def check_branches(names, main):
     that byte of b / c, u[19] = u[10] < u[20]"""
     col, vec = _cols(names, main)
     b, c, u = vec("b"), vec("c"), vec("u", 26)
-    fam = {n: col("is_" + n) == 1 for n in ("beq", "bne", "blt", "bge", "bltu", "bgeu")}
+    # BLT / BLTU share the selector is_brlt, BGE / BGEU is_brge; the value column cmp_signed tells them apart
+    signed = col("cmp_signed") == 1
+    lt_sel, ge_sel = col("is_brlt") == 1, col("is_brge") == 1
+    fam = {"beq": col("is_beq") == 1, "bne": col("is_bne") == 1, "blt": lt_sel & signed, "bltu": lt_sel & ~signed,
+           "bge": ge_sel & signed, "bgeu": ge_sel & ~signed}
     rows = np.zeros_like(fam["beq"])
     for v in fam.values():
         rows |= v
-    signed = fam["blt"] | fam["bge"]
     bw, cw = word(b), word(c)
     sb = np.where(bw >= 1 << 31, bw - (1 << 32), bw)
     sc = np.where(cw >= 1 << 31, cw - (1 << 32), cw)

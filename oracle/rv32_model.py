@@ -55,9 +55,9 @@ def decode(word, pc):
     elif op == 0x17:
         i.kind, i.rd, i.imm = "lui", rd, (pc + (word & 0xFFFFF000)) & M32
     elif op == 0x6F:
-        i.kind, i.rd, i.imm, i.tgt = "jal", rd, (pc + 4) & M32, (pc + imm_j) & M32
+        i.kind, i.rd, i.tgt = "jal", rd, (pc + imm_j) & M32          # (the link value pc + 4 is constrained by the AIR, not tabulated)
     elif op == 0x67 and f3 == 0:
-        i.kind, i.rd, i.rs1, i.imm, i.off = "jalr", rd, rs1, (pc + 4) & M32, imm_i
+        i.kind, i.rd, i.rs1, i.off = "jalr", rd, rs1, imm_i
     elif op == 0x63 and f3 in (0, 1, 4, 5, 6, 7):
         i.kind = {0: "beq", 1: "bne", 4: "blt", 5: "bge", 6: "bltu", 7: "bgeu"}[f3]
         i.rs1, i.rs2, i.tgt = rs1, rs2, (pc + imm_b) & M32
@@ -253,12 +253,12 @@ class Run:
             elif k == "lui":
                 a = ins.imm
             elif k == "jal":
-                a, nxt = ins.imm, ins.tgt
+                a, nxt = (pc + 4) & M32, ins.tgt
             elif k == "jalr":
                 t = (b + ins.off) & M32
                 if t >= ADDR_LIMIT:
                     raise Trap("jump target out of range at pc 0x%x" % pc)
-                a, nxt = ins.imm, t & ~1
+                a, nxt = (pc + 4) & M32, t & ~1
             elif k in ("beq", "bne", "blt", "bge", "bltu", "bgeu"):
                 taken = {"beq": b == c, "bne": b != c, "blt": sx(b) < sx(c), "bge": sx(b) >= sx(c), "bltu": b < c, "bgeu": b >= c}[k]
                 if taken:
@@ -423,10 +423,13 @@ def traces(run: Run, pos: int):
     cid, chip = chips["cpu"]
     n = 1 << log2ceil(len(sh["rows"]))
     cpu = np.zeros((chip.main_width, n), np.int64)
-    fam_of = dict(add="is_add", sub="is_sub", slt="is_slt", sltu="is_sltu", mul="is_mul", mulhu="is_mulhu", lui="is_lui", jal="is_jal", jalr="is_jalr",
-                  beq="is_beq", bne="is_bne", blt="is_blt", bge="is_bge", bltu="is_bltu", bgeu="is_bgeu", lw="is_lw", sw="is_sw", ecall="is_ecall",
+    # selector column of each instruction form; forms that share one carry a value column beside it
+    fam_of = dict(add="is_add", sub="is_sub", slt="is_set", sltu="is_set", mul="is_mul", mulhu="is_mulhu", lui="is_lui", jal="is_jal", jalr="is_jalr",
+                  beq="is_beq", bne="is_bne", blt="is_brlt", bge="is_brge", bltu="is_brlt", bgeu="is_brge", lw="is_lw", sw="is_sw", ecall="is_ecall",
                   lb="is_lb", lbu="is_lbu", lh="is_lh", lhu="is_lhu", sb="is_sb", sh="is_sh", alu="is_alu")
-    fam_of.update({"and": "is_and", "or": "is_or", "xor": "is_xor"})
+    fam_of.update({"and": "is_bit", "or": "is_bit", "xor": "is_bit"})
+    bit_op_of = {"and": B_AND, "or": B_OR, "xor": B_XOR}
+    signed_forms = ("slt", "blt", "bge")
     for r, row in enumerate(sh["rows"]):
         ins, a, b, c = row.ins, row.a, row.b, row.c
         put, putv = _col_setter(chip, cpu, r)
@@ -434,8 +437,9 @@ def traces(run: Run, pos: int):
         k = ins.kind
         put("clk", clk); put("pc", ins.pc); put("next_pc", row.next_pc)
         put("rd", ins.rd); put("rs1", ins.rs1); put("rs2", ins.rs2)
-        putv("imm", byts(ins.imm)); putv("off", byts(ins.off))
+        putv("imm", byts(ins.imm | ins.off))          # one immediate field: operand / constant or address offset, never both
         put("aux", ins.tgt + (ALU_CODES[ins.alu] if k == "alu" else 0))
+        put("bit_op", bit_op_of.get(k, 0)); put("cmp_signed", int(k in signed_forms))
         putv("a", byts(a)); putv("b", byts(b)); putv("c", byts(c))
         put(fam_of[k], 1)
         put("rd_en", int(ins.rd != 0)); put("imm_c", int(ins.imm_form))
@@ -510,6 +514,8 @@ def traces(run: Run, pos: int):
             lk.add(B_RANGE, s[0], s[1]); lk.add(B_RANGE, s[2], s[3]); lk.add(B_LTU, s[3], ADDR_LIMIT >> 24)
             if k == "jalr":
                 U[8] = total & 1
+                U[19], U[10], U[20] = 1, byts(a)[3], 0x78          # the link value's top byte is below 0x78 (comparator slot)
+                lk.add(B_LTU, byts(a)[3], 0x78)
             else:
                 mem_port(row.m_prev, row.m_val, row.mem)
                 lk.add(B_AND, s[0], 3)
@@ -520,8 +526,13 @@ def traces(run: Run, pos: int):
                     sb = byts(a)[0] if k == "lb" else byts(a)[1]
                     U[24], U[25] = sb, sb >> 7
                     lk.add(B_MSB, sb)
+        elif k == "jal":
+            U[19], U[10], U[20] = 1, byts(a)[3], 0x78
+            lk.add(B_LTU, byts(a)[3], 0x78)
         elif k == "ecall":
             sid = b % P
+            U[24] = int(sid == 0xF0)                               # HINT_LEN: the one call whose return value is advice
+            U[25] = 0 if sid == 0xF0 else inv(sid - 0xF0)
             U[4] = int(sid == 0)
             U[5] = inv(sid) if sid else 0
             is_commit = int(sid == 0x10)
@@ -534,7 +545,7 @@ def traces(run: Run, pos: int):
         putv("u", U)
         put("pb_hi", hi["pb"]); put("pc_hi", hi["pc"]); put("pa_hi", hi["pa"])
         lk.add(B_RANGE, hi["pb"], hi["pc"]); lk.add(B_RANGE, hi["pa"], hi["m"])
-        if k in ("add", "sub", "mul", "mulhu", "ecall"):
+        if k in ("add", "sub", "mul", "mulhu", "ecall", "jal", "jalr"):
             lk.add(B_RANGE, byts(a)[0], byts(a)[1]); lk.add(B_RANGE, byts(a)[2], byts(a)[3])
     out["cpu"] = cpu
 
@@ -684,7 +695,8 @@ def traces(run: Run, pos: int):
         k = ins.kind
         vals = dict(pc=ins.pc, rd=ins.rd, rs1=ins.rs1, rs2=ins.rs2, aux=ins.tgt + (ALU_CODES[ins.alu] if k == "alu" else 0))
         for i in range(4):
-            vals[f"imm[{i}]"], vals[f"off[{i}]"] = byts(ins.imm)[i], byts(ins.off)[i]
+            vals[f"imm[{i}]"] = byts(ins.imm | ins.off)[i]
+        vals["bit_op"], vals["cmp_signed"] = bit_op_of.get(k, 0), int(k in signed_forms)
         reads_rs2 = (k in ("beq", "bne", "blt", "bge", "bltu", "bgeu", "sb", "sh", "sw", "ecall")
                      or (not ins.imm_form and k in ("add", "sub", "and", "or", "xor", "slt", "sltu", "mul", "mulhu", "alu")))
         fl = {f: 0 for f in FLAGS}

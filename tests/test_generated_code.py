@@ -22,11 +22,11 @@ def test_air_code_is_up_to_date():
 
 
 def test_cpu_chip_shape():
-    """the numbers DESIGN.md quotes: 103 main columns (13 sponge blocks), 30 interactions = 64 permutation columns"""
+    """the numbers DESIGN.md quotes: 96 main columns = 12 sponge blocks exactly, 30 interactions = 64 permutation columns"""
     from tools.airgen import rv32
 
     cpu = next(c for c in rv32.build().chips if c.name == "cpu")
-    assert cpu.main_width == 103 and len(cpu.interactions) == 30
+    assert cpu.main_width == 96 and cpu.main_width % 8 == 0 and len(cpu.interactions) == 30
     assert 4 * ((len(cpu.interactions) + 1) // 2 + 1) == 64
 
 

@@ -213,7 +213,7 @@ def test_cpu_chip_witness_cells_are_pinned_per_family(air):
         fam = [names[i] for i in fam_cols if main[i, row] == 1]
         if not fam:
             break
-        key = (fam[0], int(main[col["imm_c"], row]))
+        key = (fam[0], int(main[col["imm_c"], row]), int(main[col["bit_op"], row]), int(main[col["cmp_signed"], row]))
         if key in seen:
             continue
         seen.add(key)
@@ -236,14 +236,18 @@ def test_cpu_chip_witness_cells_are_pinned_per_family(air):
         fam = key[0]
         if fam in ("is_mul", "is_mulhu"):            # product half, carries, and the zeros the shared U16 slots force
             assert not cells & u(*range(0, 15), 18, 19, 20, 21, 22), (key, cells)
-        if fam in ("is_and", "is_or", "is_xor"):     # operand copies of the four shared slots
+        if fam == "is_bit":                          # AND / OR / XOR: operand copies of the four shared slots
             assert not cells & u(4, 5, 6, 7, 11, 12, 13, 14, 18, 19, 20, 21, 22), (key, cells)
-        if fam in ("is_slt", "is_blt", "is_bge"):    # signed compare: byte comparison + both sign lookups
+        if fam in ("is_set", "is_brlt", "is_brge") and key[3] == 1:    # signed compare: byte comparison + both sign lookups
             assert not cells & u(0, 1, 2, 3, 9, 10, 18, 19, 20, 21, 24, 25), (key, cells)
         if fam in ("is_lw", "is_sw"):                # the memory family fills the block up to the sub-word sign columns
             assert not cells & u(*range(0, 24)), (key, cells)
         if fam in ("is_add", "is_sub"):
             assert not cells & u(0, 1, 2, 3, 18) and not cells & {"a_0", "a_1", "a_2", "a_3", "b_0", "b_3"}, (key, cells)
+        if fam in ("is_jal", "is_jalr"):             # the link value pc + 4 is constrained (bytes, top byte bound), not tabulated
+            assert not cells & {"a_0", "a_1", "a_2", "a_3"} and not cells & u(10, 19, 20), (key, cells)
+        if fam == "is_ecall":                        # t0 is unchanged by every call but HINT_LEN
+            assert not cells & {"a_0", "a_1", "a_2", "a_3"} and not cells & u(4, 6, 24), (key, cells)
 
 
 def _cpu_names():

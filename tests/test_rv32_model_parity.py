@@ -108,7 +108,7 @@ def test_hand_written_family_checks_agree_with_the_generated_checker():
         "add": ("is_add", [f"{x}[{i}]" for x in "abc" for i in range(4)] + [f"u[{i}]" for i in range(4)] + ["next_pc"]),
         "lw": ("is_lw", [f"a[{i}]" for i in range(4)] + [f"b[{i}]" for i in range(4)] + [f"u[{i}]" for i in range(24)] + ["next_pc"]),
         "mul": ("is_mul", [f"{x}[{i}]" for x in "abc" for i in range(4)] + [f"u[{i}]" for i in range(11)]),
-        "branch": ("is_bge", [f"{x}[{i}]" for x in "bc" for i in range(4)] + [f"u[{i}]" for i in (0, 1, 2, 3, 10, 19, 20)] + ["next_pc", "aux"]),
+        "branch": ("is_brge", [f"{x}[{i}]" for x in "bc" for i in range(4)] + [f"u[{i}]" for i in (0, 1, 2, 3, 10, 19, 20)] + ["next_pc", "aux"]),
     }
     wordof = lambda x, r: sum(int(main[col[f"{x}[{i}]"], r]) << (8 * i) for i in range(4))
     # rows whose operands make every listed cell matter (a product with a zero factor, or a comparison decided by the top

@@ -35,6 +35,7 @@ BUSES = {"program": 1, "byte": 2, "mem": 3, "image": 4, "pv": 5, "alu": 6}
 ALU_SLL, ALU_SRL, ALU_SRA = 1, 2, 3
 ALU_MULH, ALU_MULHSU, ALU_DIV, ALU_DIVU, ALU_REM, ALU_REMU = 4, 5, 6, 7, 8, 9
 SYS_COMMIT = 0x10
+SYS_HINT_LEN = 0xF0
 REG_A1 = 11
 
 # byte-table opcodes
@@ -42,15 +43,22 @@ B_AND, B_OR, B_XOR, B_LTU, B_MSB, B_RANGE, B_U16 = 1, 2, 3, 4, 5, 6, 7
 
 FLAGS = [
     "rd_en", "rs1_en", "rs2_en", "imm_c",
-    "is_add", "is_sub", "is_and", "is_or", "is_xor", "is_slt", "is_sltu", "is_mul", "is_mulhu",
-    "is_lui", "is_jal", "is_jalr", "is_beq", "is_bne", "is_blt", "is_bge", "is_bltu", "is_bgeu",
+    "is_add", "is_sub",
+    "is_bit",             # AND / OR / XOR: the byte-table opcode is the value column bit_op
+    "is_set",             # SLT / SLTU: signedness is the value column cmp_signed
+    "is_mul", "is_mulhu",
+    "is_lui", "is_jal", "is_jalr", "is_beq", "is_bne",
+    "is_brlt", "is_brge",  # BLT / BLTU and BGE / BGEU: signedness in cmp_signed
     "is_lw", "is_sw", "is_ecall",
     "is_lb", "is_lbu", "is_lh", "is_lhu", "is_sb", "is_sh",
     "is_alu",   # the result comes from another chip over the "alu" bus (alu_op selects it)
 ]
-# instruction tuple on the program bus: pc, rd, rs1, rs2, imm[4], off[4], aux, flags...
-# (aux = branch / jump target for the control-flow families, alu-bus opcode for is_alu rows: never both)
-N_INSTR_FIELDS = 1 + 3 + 4 + 4 + 1 + len(FLAGS)
+VALUE_FLAGS = ["bit_op", "cmp_signed"]   # decode-time values that are not 0/1 selectors of a family (0 outside their family)
+# instruction tuple on the program bus: pc, rd, rs1, rs2, imm[4], aux, bit_op, cmp_signed, flags...
+# (imm = the immediate operand, the LUI / AUIPC constant, or the address offset of loads / stores / JALR: never two of
+#  them; aux = branch / jump target for the control-flow families, alu-bus opcode for is_alu rows: never both)
+N_INSTR_FIELDS = 1 + 3 + 4 + 1 + len(VALUE_FLAGS) + len(FLAGS)
+LINK_TOP_BYTE = 0x78      # a link value pc + 4 < 0x38000004; its alias pc + 4 + p has a top byte >= 0x78
 
 PUB_START_PC, PUB_NEXT_PC, PUB_EXIT_CODE, PUB_SHARD, PUB_IS_LAST = 0, 1, 2, 3, 4
 N_PUB = 5
@@ -64,7 +72,7 @@ ADDR_TOP_BYTE = 0x38
 def build_program():
     ch = Chip("program")
     fields = [ch.prep("pc"), ch.prep("rd"), ch.prep("rs1"), ch.prep("rs2")]
-    fields += ch.preps("imm", 4) + ch.preps("off", 4) + [ch.prep("aux")]
+    fields += ch.preps("imm", 4) + [ch.prep("aux")] + [ch.prep(f) for f in VALUE_FLAGS]
     fields += [ch.prep(f) for f in FLAGS]
     mult = ch.col("mult")
     ch.receive("program", fields, mult)
@@ -90,9 +98,11 @@ def build_cpu():
     ch = Chip("cpu")
     clk, pc, next_pc = ch.col("clk"), ch.col("pc"), ch.col("next_pc")
     rd, rs1, rs2 = ch.col("rd"), ch.col("rs1"), ch.col("rs2")
-    imm, off, aux = ch.cols("imm", 4), ch.cols("off", 4), ch.col("aux")
+    imm, aux = ch.cols("imm", 4), ch.col("aux")
+    off = imm                 # loads / stores / JALR: the program table's immediate field is the address offset
     tgt = alu_op = aux
-    # Flags that are linear in other flags are expressions, not columns (104 main columns = 13 sponge blocks exactly):
+    bit_op, cmp_signed = ch.col("bit_op"), ch.col("cmp_signed")
+    # Flags that are linear in other flags are expressions, not columns (96 main columns = 12 sponge blocks exactly):
     #   is_real = sum of the family flags (a real row belongs to exactly one family; the program table, whose rows
     #             the fetch lookup must match with this very multiplicity, guarantees it);
     #   rs1_en  = every family that reads rs1;
@@ -133,9 +143,11 @@ def build_cpu():
     # on real rows the program-table lookup pins all of them
     for f in ["rd_en", "imm_c"] + FAMILY:
         ch.assert_zero((1 - is_real) * F[f])
+    ch.assert_zero((1 - is_real) * bit_op)
+    ch.assert_zero((1 - is_real) * cmp_signed)
 
     # ---------------- fetch
-    ch.send("program", [pc, rd, rs1, rs2] + imm + off + [aux] + [F[f] for f in FLAGS], is_real)
+    ch.send("program", [pc, rd, rs1, rs2] + imm + [aux, bit_op, cmp_signed] + [F[f] for f in FLAGS], is_real)
     # families that live in their own chips (shifts): the row only ships (op, a, b, c) over the alu bus;
     # the receiving chip constrains a and range-checks its bytes
     ch.send("alu", [alu_op] + a + b + c, F["is_alu"])
@@ -159,10 +171,11 @@ def build_cpu():
 
     # ---------------- families
     sel_addsub = F["is_add"] + F["is_sub"]
-    sel_bit = F["is_and"] + F["is_or"] + F["is_xor"]
-    sel_branch = F["is_beq"] + F["is_bne"] + F["is_blt"] + F["is_bge"] + F["is_bltu"] + F["is_bgeu"]
-    sel_signed = F["is_slt"] + F["is_blt"] + F["is_bge"]
-    sel_cmp = F["is_slt"] + F["is_sltu"] + sel_branch
+    sel_bit = F["is_bit"]
+    sel_branch = F["is_beq"] + F["is_bne"] + F["is_brlt"] + F["is_brge"]
+    sel_signed = cmp_signed        # (a 0/1 value of the program table, 1 only on SLT / BLT / BGE rows)
+    sel_cmp = F["is_set"] + sel_branch
+    sel_link = F["is_jal"] + F["is_jalr"]
     sel_mul = F["is_mul"] + F["is_mulhu"]
     sel_loadsub = F["is_lb"] + F["is_lbu"] + F["is_lh"] + F["is_lhu"]
     sel_mem = F["is_lw"] + F["is_sw"] + sel_loadsub + F["is_sb"] + F["is_sh"]
@@ -190,7 +203,7 @@ def build_cpu():
     x, mcy = U[0:4], U[4:11] + [Expr.const(0)]
 
     # AND / OR / XOR : four byte lookups on copies of the operand bytes
-    op_bit = B_AND * F["is_and"] + B_OR * F["is_or"] + B_XOR * F["is_xor"]
+    op_bit = bit_op
     for i in range(4):
         ch.assert_zero(sel_bit * (U[11 + i] - a[i]))
         ch.assert_zero(sel_bit * (U[4 + i] - b[i]))
@@ -218,16 +231,16 @@ def build_cpu():
     ch.assert_zero((sel_cmp - sel_signed) * msb_c)
     ch.assert_zero(sel_signed * (b3c - b[3]))
     ch.assert_zero(sel_signed * (c3c - c[3]))
-    ch.send("byte", [B_LTU * sel_cmp + B_U16 * sel_mul, lt, b_cmp, c_cmp], sel_cmp + sel_mul)          # (MUL: carry 6 in u[10])
+    # (MUL: carry 6 in u[10]; JAL / JALR: the top byte of the link value is below 0x78, see the link constraints below)
+    ch.send("byte", [B_LTU * (sel_cmp + sel_link) + B_U16 * sel_mul, lt, b_cmp, c_cmp], sel_cmp + sel_mul + sel_link)
     ch.send("byte", [B_MSB * sel_signed + B_U16 * sel_mul, msb_c, c3c, 0], sel_signed + sel_mul)        # (MUL: carry 5 in u[9])
     # (the sign of b's top byte goes through the slot [MSB, u[25], u[24], 0] of the sub-word loads, below)
-    sel_set = F["is_slt"] + F["is_sltu"]
+    sel_set = F["is_set"]
     ch.assert_zero(sel_set * (a[0] - lt))
     for i in range(1, 4):
         ch.assert_zero(sel_set * a[i])
     is_eq = 1 - any_df
-    taken = (F["is_beq"] * is_eq + F["is_bne"] * (1 - is_eq) + (F["is_blt"] + F["is_bltu"]) * lt
-             + (F["is_bge"] + F["is_bgeu"]) * (1 - lt))
+    taken = F["is_beq"] * is_eq + F["is_bne"] * (1 - is_eq) + F["is_brlt"] * lt + F["is_brge"] * (1 - lt)
     ch.assert_zero(sel_branch * (next_pc - pc - 4) - taken * (tgt - pc - 4))
 
     # MUL / MULHU : the half of the 64-bit product that is NOT the result lives in u[0..3] (x), the result half is `a`
@@ -240,10 +253,16 @@ def build_cpu():
         pk = F["is_mul"] * a[k] + F["is_mulhu"] * x[k] if k < 4 else F["is_mul"] * x[k - 4] + F["is_mulhu"] * a[k - 4]
         ch.assert_zero(sel_mul * (terms + cin - 256 * mcy[k]) - pk)
 
-    # LUI / AUIPC / JAL / JALR link : a := imm   (pc-relative constants are folded at decode time)
-    sel_const = F["is_lui"] + F["is_jal"] + F["is_jalr"]
+    # LUI / AUIPC : a := imm   (the pc-relative constant is folded at decode time)
     for i in range(4):
-        ch.assert_zero(sel_const * (a[i] - imm[i]))
+        ch.assert_zero(F["is_lui"] * (a[i] - imm[i]))
+    # JAL / JALR : a := pc + 4.  The bytes of a are range-checked (below, with the arithmetic families) and its top byte is
+    # below 0x78 through the comparator's lookup slot (u[19] = 1 = "u[10] < u[20]", u[10] = a_3, u[20] = 0x78), so the
+    # equality mod p is an equality of 32-bit values: pc + 4 < 0x38000004 and the alias pc + 4 + p starts with a byte >= 0x78
+    ch.assert_zero(sel_link * (word(a) - pc - 4))
+    ch.assert_zero(sel_link * (lt - 1))
+    ch.assert_zero(sel_link * (b_cmp - a[3]))
+    ch.assert_zero(sel_link * (c_cmp - LINK_TOP_BYTE))
     ch.assert_zero(F["is_jal"] * (next_pc - tgt))
 
     # address adder (LW, SW, JALR): u[0..3] sum bytes, u[4..7] carries
@@ -309,7 +328,7 @@ def build_cpu():
     ch.send("byte", [B_RANGE, 0, pa_hi, m_hi], is_real)      # (u[16..19] belong to the memory family only)
 
     # range check of a for the families that compute it arithmetically
-    sel_range_a = sel_addsub + sel_mul + F["is_ecall"]
+    sel_range_a = sel_addsub + sel_mul + F["is_ecall"] + sel_link
     ch.send("byte", [B_RANGE, 0, a[0], a[1]], sel_range_a)
     ch.send("byte", [B_RANGE, 0, a[2], a[3]], sel_range_a)
 
@@ -326,6 +345,14 @@ def build_cpu():
     ch.assert_zero(ec * (word(b) * id_inv - (1 - is_halt)))
     ch.assert_zero(ec * (next_pc - (1 - is_halt) * (pc + 4)))
     ch.assert_zero(ec * (is_halt * (word(c) - ch.pub(PUB_EXIT_CODE))))
+    # only HINT_LEN (id 0xF0) returns a value in t0 (advice: the length of the next stdin buffer, private input like the
+    # buffer itself); every other call leaves t0 unchanged.  u[24] = "is HINT_LEN", u[25] = 1 / (id - 0xF0)
+    is_hl, hl_inv = U[24], U[25]
+    ch.assert_zero(ec * (is_hl * (is_hl - 1)))
+    ch.assert_zero(ec * (is_hl * (word(b) - SYS_HINT_LEN)))
+    ch.assert_zero(ec * ((word(b) - SYS_HINT_LEN) * hl_inv - (1 - is_hl)))
+    for i in range(4):
+        ch.assert_zero(ec * ((1 - is_hl) * (a[i] - b[i])))
     # COMMIT (id 0x10, a0 = index, a1 = word) — SP1's syscall contract: the guest hashes the bytes
     # it wrote to fd 3 with SHA-256 and commits the eight digest words, COMMIT(k, digest word k), before HALT
     # (reference crates/finalization_prove/src/main.rs:26-32 via sp1_zkvm::io::commit).  The row reads a1 = x11 through
