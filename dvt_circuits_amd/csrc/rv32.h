@@ -341,9 +341,9 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
         }
         s.byte(B_LTU - 1, (bc << 8) | ccv);
     } else if (F(F_MUL) | F(F_MULHU)) {
-        // (carries are materialised before any lookup is issued: with the atomics interleaved into
-        //  the carry chain hipcc 7.2 fed the k = 1 lookup an unshifted accumulator on gfx950 —
-        //  caught by tests/test_gpu_k0_parity.py)
+        // (hipcc 7.2 miscompiles this carry chain for gfx950 once the k-loop is fully unrolled: carry 1 comes out as
+        //  (t0 + S1) >> 8, the accumulator unshifted.  s.fence() pins it; tools/microbench/k0_fill_repro.hip is the
+        //  standalone reproducer (this very template with a store-only sink) and tests/test_gpu_k0_parity.py the guard.)
         uint32_t pbyte[8], pcarry[8], acc = 0;
         for (int k = 0; k < 8; k++) {
             uint32_t t = acc;

@@ -38,6 +38,12 @@ struct DeviceSink {
     // quarter-rate integer multiplies; a row issues ~60 of these)
     __device__ void put(int col, uint32_t v) { cpu[(size_t)col * n + row] = p2f::to_mont((double)v); }
     // (see rv32.h: keeps hipcc from re-associating the MUL carry chain)
+    // Keeps hipcc 7.2 from miscompiling the MUL family's carry chain once its k-loop is unrolled (rv32.h).  Root cause narrowed
+    // in round 2 with tools/microbench/k0_fill_repro.hip (the real fill_cpu_row with a plain store-only sink, no LDS / ballots /
+    // atomics): wrong at -O2 / -O3 (carry k = 1 is computed from the UNSHIFTED accumulator: (t0 + S1) >> 8 instead of
+    // ((t0 >> 8) + S1) >> 8), right at -O1, right with -fno-unroll-loops, unaffected by -amdgpu-sdwa-peephole=0 and
+    // -amdgpu-codegenprepare-mul24=0, and the bare loop alone (k0_carry_repro.hip) compiles correctly: a gfx950 code-generation
+    // bug after full unrolling, not the lookup-counting fast path below.
     __device__ void fence(uint32_t &v) { asm volatile("" : "+v"(v)); }
 
     __device__ void global_add(uint32_t key, uint32_t cnt) {
