@@ -87,8 +87,9 @@ def test_world_size_2_header_exchange_and_common_challenges():
 
 
 def test_bench_line_fields_of_committed_profile():
-    """the committed round-1 bench line carries every field of the contract"""
-    line = json.load(open(os.path.join(ROOT, "profiles", "r1c_bench_line.json")))
+    """the committed bench line of the round carries every field of the contract"""
+    line = json.load(open(os.path.join(ROOT, "profiles", "r2_bench_line.json")))
+    assert "whole boundary call" in line["config"]["measured_unit"] and line["config"]["shards_per_step"] >= 32
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in line, k

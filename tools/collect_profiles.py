@@ -56,6 +56,6 @@ for name, label, corr in (("void dvt::ntt_strided_kernel<true>", "P1 ntt_strided
     total += rd * corr + wr
 json.dump(dict(k1_hbm_bytes_per_proof=total, proofs_in_run=n_proofs,
                method="rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE over `bench.py --no-cpu-baseline "
-                      "--steps 1 --warmup 0`; counters are KiB; FETCH_SIZE x2 on lde_block only (wide contiguous reads, gfx950), see tools/collect_profiles.py",
+                      "--steps 1 --warmup 0 --shards-per-gpu 4`; counters are KiB; FETCH_SIZE x2 on lde_block only (wide contiguous reads, gfx950), see tools/collect_profiles.py",
                kernels=k1), open(os.path.join(ROOT, f"{tag}_pmc_k1_traffic.json"), "w"), indent=1)
 print("K1 HBM bytes per proof: %.3f GB" % (total / 1e9))
