@@ -357,3 +357,29 @@ def test_mem_init_address_order_holds_over_the_integers(air):
     m2[19, n_real] = 1
     assert air.check_constraints(mi["chip_id"], m2, mi["prep"], pubs)[0] == 0
     assert air.logup_unbalanced([dict(mi, main=m2) if ch is mi else ch for ch in chips], pubs)[0] > 0
+
+
+def test_empty_public_values_commit_the_golden_digest_words():
+    """SURVEY.md App. B.3 (probe of the reference's bundled SP1 guest): a guest that writes no public values COMMITs the words
+    42c4b0e3 141cfc98 c8f4fb9a 24b96f99 e441ae27 4c939b64 1b9995a4 55b85278 = SHA-256("") read as little-endian u32s, with
+    COMMIT(index, word).  The SP1-ABI exit path of the test guests reproduces exactly that, in the product's executor and in the
+    oracle's independent machine."""
+    from oracle import rv32_model
+
+    golden = [0x42c4b0e3, 0x141cfc98, 0xc8f4fb9a, 0x24b96f99, 0xe441ae27, 0x4c939b64, 0x1b9995a4, 0x55b85278]
+    elf = guests.commit_only(b"")
+    rc, rep, pv, err = capi.execute(elf)
+    assert rc == 0 and pv == b"", err
+    run = rv32_model.Run(elf)
+    assert run.halted and run.public_values == b"" and [run.committed[k] for k in range(8)] == golden
+    assert run.cycles == rep["cycles"]
+    # and the eight COMMIT rows of the product's trace carry (index k, word k): a0 in c, a1 through the memory port
+    chips, pubs, _ = capi.rv32_debug_traces(elf)
+    names = _cpu_names()
+    col = {n: i for i, n in names.items()}
+    cpu = next(c for c in chips if c["main"].shape[0] == len(names))["main"]
+    rows = [r for r in range(cpu.shape[1]) if cpu[col["commit_m"], r] == 1]
+    assert len(rows) == 8
+    for k, r in enumerate(rows):
+        assert sum(int(cpu[col[f"c_{i}"], r]) << (8 * i) for i in range(4)) == k
+        assert sum(int(cpu[col[f"u_{9 + i}"], r]) << (8 * i) for i in range(4)) == golden[k]
