@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--participants", type=int, default=0, help="0 = the reference's finalization example (n = 3); N = synthetic N-participant "
                     "input of the same format (tools/gen_dkg_input.py), e.g. 255")
     ap.add_argument("--batch", type=int, default=0, help="B independent single-shard proofs round-robin over the ranks instead of one sharded execution")
+    ap.add_argument("--batch-streams", type=int, default=3, help="--batch: prover handles (one host thread + HIP stream each) per GPU")
     ap.add_argument("--exec-threads", type=int, default=0)
     ap.add_argument("--cpu-sizes", type=int, nargs=2, default=[20, 60])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -173,14 +174,32 @@ def main():
             proof, rep = prover.prove_core(pk, [inputs[mine[0]]])
             ok, ec, pv, why = capi.verify(vk, proof, 100, 16)
             assert ok and ec == 0 and pv == guests.dkg_like_expected(inputs[mine[0]], "finalization", *consts), f"bench proof rejected: {why}"
+        # S prover handles on this GPU, one host thread each: the host-side execution / upload / proof download of one
+        # proof overlaps the kernels of another (independent proofs share nothing; ctypes drops the GIL during the call)
+        import threading
+
+        lanes = [(prover, pk)]
+        for _ in range(1, max(1, args.batch_streams)):
+            h = capi.Prover(cfg)
+            lanes.append((h, h.setup(elf)[0]))
         cyc_mine = 0
 
         def step():
             nonlocal cyc_mine
-            cyc_mine = 0
-            for i in mine:
-                _, rep = prover.prove_core(pk, [inputs[i]])
-                cyc_mine += int(rep["cycles"])
+            done = [0] * len(lanes)
+
+            def lane(k):
+                h, hpk = lanes[k]
+                for i in mine[k::len(lanes)]:
+                    _, rep = h.prove_core(hpk, [inputs[i]])
+                    done[k] += int(rep["cycles"])
+
+            th = [threading.Thread(target=lane, args=(k,)) for k in range(len(lanes))]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            cyc_mine = sum(done)
 
         for _ in range(args.warmup):
             step()
@@ -199,7 +218,10 @@ def main():
         workload = ("BASELINE configs[4] shape: batch of %d independent single-shard proofs of the finalization-shaped guest, each on the "
                     "reference's example input with its own gen_id, round-robin over %d rank(s), no collective" % (args.batch, world))
         extra["proofs_per_hour"] = args.batch * args.steps * 3600.0 / dt
-        parallelism = "independent proofs, proof i on GPU i mod %d (replicas only)" % world
+        parallelism = "independent proofs, proof i on GPU i mod %d (replicas only), %d prover handles (host threads) per GPU" % (world, len(lanes))
+        for h, hpk in lanes[1:]:
+            h.pk_free(hpk)
+            h.close()
     else:
         # ---------------------------------------------------------------- one execution, shard-parallel
         total_shards = args.shards_per_gpu * world

@@ -103,6 +103,48 @@ def test_config4_batch_of_independent_proofs(gpu):
     gpu.pk_free(pk)
 
 
+def test_config4_concurrent_handles_reproduce_the_sequential_bytes(gpu):
+    """bench.py --batch runs several prover handles of one GPU from their own host threads: every proof made that way is
+    byte-identical to the one the single handle makes alone (handles share no mutable state)"""
+    import threading
+
+    from dvt_circuits_amd import capi
+
+    example = json.load(open(os.path.join(ROOT, "tests", "golden", "finalization_example.json")))
+    elf = guests.dkg_like("finalization")
+    bufs = []
+    for i in range(4):
+        doc = dict(example, settings=dict(example["settings"], gen_id=hashlib.sha256(b"conc%d" % i).digest()[:16].hex()))
+        bufs.append(capi.stdin_from_json("finalization", json.dumps(doc).encode()))
+    pk, vk = gpu.setup(elf)
+    want = [gpu.prove_core(pk, [b])[0] for b in bufs]
+    gpu.pk_free(pk)
+    handles = [capi.Prover("{}") for _ in range(2)]
+    got, errs = [None] * len(bufs), []
+
+    def lane(k):
+        try:
+            h = handles[k]
+            hpk, _ = h.setup(elf)
+            for rep in range(2):                                    # twice: pooled buffers are reused across proofs
+                for i in range(k, len(bufs), 2):
+                    got[i] = h.prove_core(hpk, [bufs[i]])[0]
+            h.pk_free(hpk)
+        except Exception as e:                                      # noqa: BLE001 - reported by the assert below
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=lane, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for h in handles:
+        h.close()
+    assert not errs, errs
+    assert got == want
+    assert capi.verify(vk, got[3])[0]
+
+
 def test_bench_batch_mode_line():
     """bench.py --batch (BASELINE configs[4], replicas only) end to end, small B"""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
