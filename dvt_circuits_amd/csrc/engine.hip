@@ -422,7 +422,7 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
         max_log_n = std::max(max_log_n, t.log_n);
         size_t w = std::max<size_t>({(size_t)s.d->main_w, (size_t)4 * s.d->perm_ext_w, 4});
         max_mat_words = std::max(max_mat_words, w * s.n);
-        need += (size_t)(s.d->main_w * 2 + 4 * s.d->perm_ext_w * 3 + 8 * 3) * s.n * 4 + 16 * 256;
+        need += (size_t)(s.d->main_w * 2 + 4 * s.d->perm_ext_w * 3 + 4 + 8 * 3) * s.n * 4 + 16 * 256;
     }
     if (cs.empty()) return fail("prove: no chips");
     for (auto &pc : pk.prep) {
@@ -527,12 +527,14 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
         const size_t bw = 4 * (size_t)s.d->perm_ext_w;
         ALLOC(s.perm, uint32_t, bw * s.n);
         ALLOC(s.perm_lde, uint32_t, bw * 2 * s.n);
-        PermArgs pa{s.main, s.prep, d_pub, s.perm, d_beta, d_beta_f64, perm_alpha, s.log_n};
+        uint32_t *totals, *scan_scratch;
+        ALLOC(totals, uint32_t, 4 * s.n);
+        PermArgs pa{s.main, s.prep, d_pub, s.perm, totals, d_beta, d_beta_f64, perm_alpha, s.log_n};
         HIPCHK(s.d->launch_perm(stream, pa));
-        uint32_t *phi = s.perm + (bw - 4) * s.n;
-        uint32_t *scan_scratch;
         ALLOC(scan_scratch, uint32_t, prefix_sum_scratch_words(4, s.n));
-        HIPCHK(launch_prefix_sum_columns(stream, phi, 4, s.n, scan_scratch));
+        HIPCHK(launch_prefix_sum_columns(stream, totals, 4, s.n, scan_scratch));
+        HIPCHK(launch_phi_from_prefix_sums(stream, totals, s.perm + (bw - 4) * s.n, s.log_n));
+        const uint32_t *phi = totals;   // (the cumulative sum = the last inclusive prefix sum)
         // the cumulative sum is only needed for the transcript, after the permutation tree: its four words are copied
         // asynchronously into the tail of the pinned staging buffer and read after the next synchronisation
         uint32_t *cw = reinterpret_cast<uint32_t *>(h_down + DOWN_BYTES - 4096) + 4 * n_cumsum++;
@@ -578,7 +580,7 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
         QuotientArgs qa;
         qa.main_lde = s.main_lde; qa.prep_lde = s.prep_lde; qa.perm_lde = s.perm_lde; qa.pub = d_pub; qa.out = s.quot;
         qa.alpha_pows = d_alpha; qa.beta_pows = d_beta; qa.alpha_d = d_alpha_f64; qa.beta_d = d_beta_f64;
-        qa.perm_alpha = perm_alpha; qa.cumsum = s.cumsum;
+        qa.perm_alpha = perm_alpha; qa.cum_over_n = s.cumsum * inv(Fp::from_canonical((uint32_t)s.n));
         Fp gn = pow(g, s.n);
         qa.z_even = gn - Fp::one();
         qa.z_odd = -gn - Fp::one();

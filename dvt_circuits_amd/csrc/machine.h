@@ -28,7 +28,7 @@ struct VerifierAccess {
 
 struct VerifierPoint {
     const Fp4 *alpha_pows, *beta_pows;
-    Fp4 perm_alpha, cumsum, sel_first, sel_last, sel_trans;
+    Fp4 perm_alpha, cum_over_n, sel_first, sel_last, sel_trans;
 };
 
 struct ChipDesc {
@@ -78,7 +78,7 @@ Fp4 verify_eval_t(const VerifierAccess &ax, const VerifierPoint &pt) {
     f.alpha_pows = pt.alpha_pows;
     f.beta_pows = pt.beta_pows;
     f.perm_alpha = pt.perm_alpha;
-    f.cumsum = pt.cumsum;
+    f.cum_over_n = pt.cum_over_n;
     f.sel_first = pt.sel_first;
     f.sel_last = pt.sel_last;
     f.sel_trans = pt.sel_trans;

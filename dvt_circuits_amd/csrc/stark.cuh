@@ -6,13 +6,17 @@
 //     the LogUp permutation row (K4).
 //   - kernel templates instantiated per generated Air struct (gen/air_*.inc).
 //
-// LogUp layout of a chip with n interactions: nb = ceil(n/2) batch columns then
-// one running-sum column phi, all in F_p^4, stored flattened as 4(nb+1) base
-// columns.  For a batch {j0,j1}: perm_b * d_j0 * d_j1 = s_j0 m_j0 d_j1 + s_j1 m_j1 d_j0
-// with d_j = alpha_p + bus_j + sum_k beta^(k+1) v_jk;  phi is the inclusive prefix
-// sum of the row totals, phi[last] = the chip's cumulative sum.
-// Constraint numbering (powers of alpha): the chip's own constraints 0..C-1, then
-// batch b -> C+b, then phi-first C+nb, phi-transition C+nb+1, phi-last C+nb+2.
+// LogUp layout of a chip with n interactions in nb = ceil(n/2) batches (pairs): one
+// column per batch EXCEPT THE LAST, then the running-sum column phi, all in F_p^4,
+// stored flattened as 4 nb base columns.  With d_j = alpha_p + bus_j + sum_k beta^(k+1) v_jk
+// a batch {j0,j1} satisfies  v_b * d_j0 * d_j1 = s_j0 m_j0 d_j1 + s_j1 m_j1 d_j0,  where v_b is
+// its column, and for the last batch the expression
+//     v_last = phi[r+1] - phi[r] - sum_{b < nb-1} perm_b[r] + S/N      (r+1 cyclic: row N-1 -> row 0)
+// with S = the chip's cumulative sum and N its height: phi is the exclusive prefix sum of
+// (row total - S/N), so the differences around the cycle add up to zero exactly when the row totals
+// add up to S.  No boundary constraint and no selector is needed (the constraint has degree 3 on every row),
+// and the last batch costs no column.
+// Constraint numbering (powers of alpha): the chip's own constraints 0..C-1, then batch b -> C+b.
 //
 // (stock SP1 keeps this in sp1-stark, absent.)
 #pragma once
@@ -30,9 +34,10 @@ DVT_HD Fp4 to_ext(const Fp4 &a) { return a; }
 template <class Air>
 struct PermShape {
     static constexpr int NB = (Air::N_INTERACTIONS + 1) / 2;
-    static constexpr int EXT_W = Air::N_INTERACTIONS ? NB + 1 : 0;  // ext columns
+    static constexpr int EXT_W = Air::N_INTERACTIONS ? NB : 0;  // ext columns: NB - 1 batches + phi
+    static constexpr int PHI = NB - 1;                          // index of phi
     static constexpr int BASE_W = 4 * EXT_W;
-    static constexpr int N_FOLDED = Air::N_CONSTRAINTS + (Air::N_INTERACTIONS ? NB + 3 : 0);
+    static constexpr int N_FOLDED = Air::N_CONSTRAINTS + (Air::N_INTERACTIONS ? NB : 0);
 };
 
 // Access must provide: T main(col,rot), T prep(col,rot), T pub(k),
@@ -51,7 +56,7 @@ struct ConstraintFolder {
     DotAcc4 acc_d;
     Fp4 perm_alpha;
     T sel_first, sel_last, sel_trans;
-    Fp4 cumsum;
+    Fp4 cum_over_n;   // S / N
     Fp4 acc;
     // pending first half of a LogUp batch
     T pend_m;
@@ -116,8 +121,15 @@ struct ConstraintFolder {
         d.c[0] += (double)bus;
         return d;
     }
+    // value of batch b: its column, or (last batch) the running-sum difference that stands for it
+    DVT_HD Fp4 batch_value(int b) const {
+        if (b < Shape::PHI) return ax.perm(b, 0);
+        Fp4 v = ax.perm(Shape::PHI, 1) - ax.perm(Shape::PHI, 0) + cum_over_n;
+        for (int k = 0; k < Shape::PHI; k++) v -= ax.perm(k, 0);
+        return v;
+    }
     DVT_HD Fd4 perm_c(int e) const {
-        const Fp4 p = ax.perm(e, 0);
+        const Fp4 p = batch_value(e);
         Fd4 r;
         for (int k = 0; k < 4; k++) r.c[k] = centred_from_mont(p.c[k].v);
         return r;
@@ -152,31 +164,19 @@ struct ConstraintFolder {
             pend_m = m;
             pend_d = d;
             if (j == Air::N_INTERACTIONS - 1) {  // odd tail: perm * d - m = 0
-                Fp4 p = ax.perm(j >> 1, 0);
+                Fp4 p = batch_value(j >> 1);
                 fold(Air::N_CONSTRAINTS + (j >> 1), p * d - to_ext(m));
             }
         } else {
-            Fp4 p = ax.perm(j >> 1, 0);
+            Fp4 p = batch_value(j >> 1);
             Fp4 lhs = p * pend_d * d;
             Fp4 rhs = d * pend_m + pend_d * m;
             fold(Air::N_CONSTRAINTS + (j >> 1), lhs - rhs);
         }
     }
 
-    DVT_HD void finish_logup() {
-        if (Air::N_INTERACTIONS == 0) return;
-        constexpr int NB = Shape::NB;
-        Fp4 phi_l = ax.perm(NB, 0), phi_n = ax.perm(NB, 1);
-        Fp4 sum_l = Fp4::zero(), sum_n = Fp4::zero();
-        for (int b = 0; b < NB; b++) { sum_l += ax.perm(b, 0); sum_n += ax.perm(b, 1); }
-        const int base = Air::N_CONSTRAINTS + NB;
-        fold(base + 0, (phi_l - sum_l) * sel_first);
-        fold(base + 1, (phi_n - phi_l - sum_n) * sel_trans);
-        fold(base + 2, (phi_l - cumsum) * sel_last);
-    }
-
     // PART < 0: everything (the host verifier).  0 <= PART < Air::N_PARTS: that group of the chip's own constraints;
-    // N_PARTS <= PART < N_PARTS + N_LPARTS: that group of LogUp batches (the last one also the running-sum constraints).
+    // N_PARTS <= PART < N_PARTS + N_LPARTS: that group of LogUp batches.
     // The folded value is the sum over the parts.
     template <int PART = -1>
     DVT_HD Fp4 run() {
@@ -185,12 +185,10 @@ struct ConstraintFolder {
         if constexpr (PART < 0) {
             Air::constraints(*this);
             Air::interactions(*this);
-            finish_logup();
         } else if constexpr (PART < Air::N_PARTS) {
             Air::template constraints_part<PART>(*this);
         } else {
             Air::template interactions_part<PART - Air::N_PARTS>(*this);
-            if constexpr (PART == Air::N_PARTS + Air::N_LPARTS - 1) finish_logup();
         }
         if constexpr (BASE) {
             acc += acc_d.value();
@@ -208,7 +206,8 @@ struct PermArgs {
     const uint32_t *main;  // [MAIN_W][N]
     const uint32_t *prep;  // [PREP_W][N]
     const uint32_t *pub;   // device public values (Montgomery)
-    uint32_t *perm;        // [4*EXT_W][N] out
+    uint32_t *perm;        // [4*EXT_W][N] out: the batch columns (the phi columns are filled from `totals` afterwards)
+    uint32_t *totals;      // [4][N] out: row totals (all batches)
     const Fp4 *beta_pows;  // device
     const double *beta_d;  // the same powers as centred doubles [..][4] (f64dot.cuh)
     Fp4 perm_alpha;
@@ -243,7 +242,7 @@ struct PermRowCtx {
         }
         if ((j & 1) == 0) batch = term; else batch += term;
         if ((j & 1) || j == Air::N_INTERACTIONS - 1) {
-            store_ext(j >> 1, batch);
+            if ((j >> 1) < PermShape<Air>::PHI) store_ext(j >> 1, batch);   // the last batch has no column
             total += batch;
         }
     }
@@ -255,7 +254,8 @@ __global__ void __launch_bounds__(256) perm_rows_kernel(PermArgs a) {
     if (row >= ((size_t)1 << a.log_n)) return;
     PermRowCtx<Air> ctx(a, row);
     Air::interactions(ctx);
-    ctx.store_ext(PermShape<Air>::NB, ctx.total);  // row total; the scan turns it into phi
+#pragma unroll
+    for (int k = 0; k < 4; k++) a.totals[(size_t)k * ctx.n + row] = ctx.total.c[k].v;   // scanned into phi afterwards
 }
 
 // ------------------------------------------------------------------ K5: quotient
@@ -268,7 +268,7 @@ struct QuotientArgs {
     const Fp4 *alpha_pows;
     const Fp4 *beta_pows;
     const double *alpha_d, *beta_d;   // centred doubles [..][4]
-    Fp4 perm_alpha, cumsum;
+    Fp4 perm_alpha, cum_over_n;   // cum_over_n = the chip's cumulative sum / N
     Fp zinv_even, zinv_odd;    // 1 / Z_H(x) on even / odd LDE rows
     Fp z_even, z_odd;          // Z_H(x) itself
     Fp w_inv;                  // omega_N^-1
@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
     f.alpha_d = a.alpha_d;
     f.beta_d = a.beta_d;
     f.perm_alpha = a.perm_alpha;
-    f.cumsum = a.cumsum;
+    f.cum_over_n = a.cum_over_n;
     // x = g * w_{2N}^i
     const uint32_t log_m = a.log_n + 1;
     Fp x = Fp::raw(a.tabs.sh_lo[1]) * (Fp::raw(a.tabs.tw_hi[((uint32_t)i << (24 - log_m)) >> 12]) *

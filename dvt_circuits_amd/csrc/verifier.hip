@@ -156,7 +156,7 @@ std::string verify_shard(const VerifyingKey &vk, const ShardProof &pf, const Sta
         pt.alpha_pows = alpha_pows.data();
         pt.beta_pows = beta_pows.data();
         pt.perm_alpha = perm_alpha;
-        pt.cumsum = o.cumsum;
+        pt.cum_over_n = o.cumsum * inv(Fp::from_canonical((uint32_t)n));
         Fp w_inv = inv(two_adic_generator(o.log_n));
         Fp4 zh = pow(zeta, n) - Fp::one();
         Fp4 d1 = zeta - Fp::one(), d2 = zeta - w_inv;

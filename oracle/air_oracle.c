@@ -126,16 +126,20 @@ size_t orc_multiset_unbalanced(const orc_multiset *ms, uint32_t *out, size_t out
     return bad;
 }
 
-/* ---------------------------------------------------------------- K4 restatement */
+/* ---------------------------------------------------------------- K4 restatement
+ * Layout: nb = ceil(n_interactions / 2) batches; one F_p^4 column per batch except the last,
+ * then phi.  phi[r] = sum_{r' < r} total[r'] - r * S / N with total = the sum of ALL batches of a row and S = the
+ * chip's cumulative sum: the last batch is the difference phi[r+1] - phi[r] - (the other batches) + S / N. */
 void orc_perm_trace(const orc_chip_air *chip, const uint32_t *main, const uint32_t *prep, uint32_t log_n,
                     const uint32_t *pub, const uint32_t alpha[4], const uint32_t beta[4], uint32_t *perm_out,
                     uint32_t cumsum_out[4]) {
     size_t n = (size_t)1 << log_n;
-    uint32_t ni = chip->n_interactions, nb = (ni + 1) / 2;
+    uint32_t ni = chip->n_interactions, nb = (ni + 1) / 2, phi_col = nb - 1;
     ef_t al, be;
     memcpy(al.c, alpha, 16);
     memcpy(be.c, beta, 16);
     ef_t *bp = malloc(sizeof(ef_t) * (chip->max_arity + 1));
+    ef_t *totals = malloc(sizeof(ef_t) * n);
     bp[0] = be;
     for (uint32_t k = 1; k < chip->max_arity; k++) bp[k] = ef_mul(bp[k - 1], be);
 #pragma omp parallel
@@ -145,7 +149,7 @@ void orc_perm_trace(const orc_chip_air *chip, const uint32_t *main, const uint32
     uint32_t *mult = malloc(4 * (ni + 1)), *vals = malloc(4 * (size_t)(ni + 1) * chip->max_arity);
 #pragma omp for schedule(static)
     for (size_t r = 0; r < n; r++) {
-        ef_t phi = ef_zero();  /* row total; turned into the running sum below */
+        ef_t total = ef_zero();
         size_t rn = (r + 1) & (n - 1);
         gather_row(main, chip->main_w, n, r, ml);
         gather_row(main, chip->main_w, n, rn, mn);
@@ -161,20 +165,23 @@ void orc_perm_trace(const orc_chip_air *chip, const uint32_t *main, const uint32
                 ef_t t = ef_mul_base(ef_inv(d), mult[j]);
                 acc = chip->inter[j].sign > 0 ? ef_add(acc, t) : ef_sub(acc, t);
             }
-            for (int k = 0; k < 4; k++) perm_out[(size_t)(4 * b + k) * n + r] = acc.c[k];
-            phi = ef_add(phi, acc);
+            if (b < phi_col)
+                for (int k = 0; k < 4; k++) perm_out[(size_t)(4 * b + k) * n + r] = acc.c[k];
+            total = ef_add(total, acc);
         }
-        for (int k = 0; k < 4; k++) perm_out[(size_t)(4 * nb + k) * n + r] = phi.c[k];
+        totals[r] = total;
     }
     free(ml); free(mn); free(pl); free(pn); free(mult); free(vals);
     }
+    ef_t sum = ef_zero();
+    for (size_t r = 0; r < n; r++) sum = ef_add(sum, totals[r]);
+    const ef_t step = ef_mul_base(sum, bb_inv((bb_t)(n % BB_P)));     /* S / N */
     ef_t run = ef_zero();
     for (size_t r = 0; r < n; r++) {
-        ef_t t;
-        for (int k = 0; k < 4; k++) t.c[k] = perm_out[(size_t)(4 * nb + k) * n + r];
-        run = ef_add(run, t);
-        for (int k = 0; k < 4; k++) perm_out[(size_t)(4 * nb + k) * n + r] = run.c[k];
+        for (int k = 0; k < 4; k++) perm_out[(size_t)(4 * phi_col + k) * n + r] = run.c[k];
+        run = ef_sub(ef_add(run, totals[r]), step);
     }
-    memcpy(cumsum_out, run.c, 16);
+    memcpy(cumsum_out, sum.c, 16);
     free(bp);
+    free(totals);
 }

@@ -25,8 +25,9 @@ void orc_quotient(const orc_chip_air *chip, const uint32_t *main_lde, const uint
                   const uint32_t alpha[4], const uint32_t cumsum[4], uint32_t *out) {
     const size_t n = (size_t)1 << log_n, m = 2 * n;
     const uint32_t ni = chip->n_interactions, nb = (ni + 1) / 2, nc = chip->n_constraints;
-    const uint32_t nfold = nc + (ni ? nb + 3 : 0);
-    ef_t al = ef_load(alpha), be = ef_load(beta), pa = ef_load(perm_alpha), cs = ef_load(cumsum);
+    const uint32_t nfold = nc + (ni ? nb : 0), phi_col = nb - 1;
+    ef_t al = ef_load(alpha), be = ef_load(beta), pa = ef_load(perm_alpha);
+    const ef_t cs_over_n = ef_mul_base(ef_load(cumsum), bb_inv((bb_t)(n % BB_P)));
     ef_t *apow = malloc(sizeof(ef_t) * (nfold + 1)), *bpow = malloc(sizeof(ef_t) * (chip->max_arity + 1));
     apow[0] = ef_one();
     for (uint32_t k = 1; k < nfold; k++) apow[k] = ef_mul(apow[k - 1], al);
@@ -60,13 +61,21 @@ void orc_quotient(const orc_chip_air *chip, const uint32_t *main_lde, const uint
         }
         if (ni) {
             chip->interactions(ml, mn, pl, pn, pub, mult, vals);
-            ef_t sum_l = ef_zero(), sum_n = ef_zero();
+            /* value of the last batch: phi' - phi - (the other batches) + S / N  (it has no column) */
+            ef_t last;
+            for (int k = 0; k < 4; k++)
+                last.c[k] = bb_sub(perm_lde[(size_t)(4 * phi_col + k) * m + inx], perm_lde[(size_t)(4 * phi_col + k) * m + i]);
+            last = ef_add(last, cs_over_n);
+            for (uint32_t b = 0; b < phi_col; b++) {
+                ef_t pcol;
+                for (int k = 0; k < 4; k++) pcol.c[k] = perm_lde[(size_t)(4 * b + k) * m + i];
+                last = ef_sub(last, pcol);
+            }
             for (uint32_t b = 0; b < nb; b++) {
-                ef_t pcol, pnext;
-                for (int k = 0; k < 4; k++) { pcol.c[k] = perm_lde[(size_t)(4 * b + k) * m + i]; pnext.c[k] = perm_lde[(size_t)(4 * b + k) * m + inx]; }
-                sum_l = ef_add(sum_l, pcol);
-                sum_n = ef_add(sum_n, pnext);
-                /* perm_b * prod(d_j) - sum_j s_j m_j prod_{k != j} d_k */
+                ef_t pcol = last;
+                if (b < phi_col)
+                    for (int k = 0; k < 4; k++) pcol.c[k] = perm_lde[(size_t)(4 * b + k) * m + i];
+                /* v_b * prod(d_j) - sum_j s_j m_j prod_{k != j} d_k */
                 ef_t d[2];
                 bb_t sm[2];
                 uint32_t cnt = 0;
@@ -81,11 +90,6 @@ void orc_quotient(const orc_chip_air *chip, const uint32_t *main_lde, const uint
                 else cons = ef_sub(ef_mul(pcol, d[0]), ef_from_base(sm[0]));
                 acc = ef_add(acc, ef_mul(apow[nc + b], cons));
             }
-            ef_t phi_l, phi_n;
-            for (int k = 0; k < 4; k++) { phi_l.c[k] = perm_lde[(size_t)(4 * nb + k) * m + i]; phi_n.c[k] = perm_lde[(size_t)(4 * nb + k) * m + inx]; }
-            acc = ef_add(acc, ef_mul(apow[nc + nb], ef_mul_base(ef_sub(phi_l, sum_l), sel_first)));
-            acc = ef_add(acc, ef_mul(apow[nc + nb + 1], ef_mul_base(ef_sub(ef_sub(phi_n, phi_l), sum_n), sel_trans)));
-            acc = ef_add(acc, ef_mul(apow[nc + nb + 2], ef_mul_base(ef_sub(phi_l, cs), sel_last)));
         }
         ef_t q = ef_mul_base(acc, bb_inv(zh));
         uint32_t *o = out + ((i & 1) ? 4 * n : 0) + (i >> 1);

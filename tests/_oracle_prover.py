@@ -159,7 +159,7 @@ def prove_shard(machine, chips, pubs, num_queries, pow_bits, perm_challenges=Non
         d = air.chip(ch["chip_id"])
         n = ch["main"].shape[1]
         cs.append(dict(id=ch["chip_id"], d=d, log_n=int(n).bit_length() - 1, n=n, main=_a(ch["main"]),
-                       prep=_a(ch["prep"]) if d.prep_w else None, ext_w=((d.n_interactions + 1) // 2 + 1) if d.n_interactions else 0))
+                       prep=_a(ch["prep"]) if d.prep_w else None, ext_w=((d.n_interactions + 1) // 2) if d.n_interactions else 0))
     hmax = max(c["log_n"] for c in cs) + 1
 
     def commit(mats):

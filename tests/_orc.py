@@ -173,7 +173,7 @@ class AirOracle:
         ch = self.chips[cid]
         n = main.shape[1]
         log_n = int(n).bit_length() - 1
-        w = 4 * ((ch.n_interactions + 1) // 2 + 1)
+        w = 4 * ((ch.n_interactions + 1) // 2)     # batches but the last, then phi (oracle/air_oracle.c)
         out = np.zeros((w, n), np.uint32)
         cs = np.zeros(4, np.uint32)
         a, b = self._arr(alpha), self._arr(beta)
