@@ -36,8 +36,8 @@ enum Flag : uint32_t {
     F_LUI, F_JAL, F_JALR, F_BEQ, F_BNE, F_BLT, F_BGE, F_BLTU, F_BGEU, F_LW, F_SW, F_ECALL,
     F_LB, F_LBU, F_LH, F_LHU, F_SB, F_SH, F_ALU, N_FLAGS
 };
-constexpr uint32_t B_AND = 1, B_OR = 2, B_XOR = 3, B_LTU = 4, B_MSB = 5, B_RANGE = 6, B_U16 = 7;
-constexpr int N_BYTE_OPS = 7;  // multiplicity columns of the byte chip, in this order: and or xor ltu msb range u16
+constexpr uint32_t B_AND = 1, B_OR = 2, B_XOR = 3, B_LTU = 4, B_MSB = 5, B_RANGE = 6, B_U16 = 7, B_ADDR = 8;
+constexpr int N_BYTE_OPS = 8;  // multiplicity columns of the byte chip, in this order: and or xor ltu msb range u16 addr
 constexpr uint32_t ADDR_LIMIT = 0x38000000u;  // tools/airgen/rv32.py ADDR_TOP_BYTE: address + address gap stays below p
 constexpr uint32_t SYS_COMMIT = 0x10;
 constexpr uint32_t REG_A1 = 11;
@@ -359,8 +359,8 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
         for (int i = 0; i < 4; i++) s.put(U + i, pbyte[xo + i]);
         for (int k = 0; k < 7; k++) s.put(U + 4 + k, pcarry[k]);
         for (int k = 0; k < 7; k++) s.byte(B_U16 - 1, pcarry[k]);
-        s.byte(B_RANGE - 1, (pbyte[xo] << 8) | pbyte[xo + 1]);
-        s.byte(B_RANGE - 1, (pbyte[xo + 2] << 8) | pbyte[xo + 3]);
+        s.byte(B_RANGE - 1, (pbyte[xo + 1] << 8) | pbyte[xo + 2]);   // (the two lookups of the address adder's sum bytes)
+        s.byte(B_RANGE - 1, (pbyte[xo] << 8) | pbyte[xo + 3]);
     } else if (F(F_LW) | F(F_SW) | F(F_JALR) | F(F_LB) | F(F_LBU) | F(F_LH) | F(F_LHU) | F(F_SB) | F(F_SH)) {
         uint32_t sum = b + in.off, cin = 0;
         for (int i = 0; i < 4; i++) {
@@ -369,9 +369,10 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
             s.put(U + i, t & 0xff);
             s.put(U + 4 + i, cin);
         }
-        s.byte(B_RANGE - 1, (B(sum, 0) << 8) | B(sum, 1));
-        s.byte(B_RANGE - 1, (B(sum, 2) << 8) | B(sum, 3));
-        s.byte(B_LTU - 1, (B(sum, 3) << 8) | (ADDR_LIMIT >> 24));
+        // [RANGE, 0, s1, s2] and [ADDR, s0 & 3, s0, s3]: byte ranges, top byte below 0x38, byte offset (u[21..23] one-hot)
+        s.byte(B_RANGE - 1, (B(sum, 1) << 8) | B(sum, 2));
+        s.byte(B_ADDR - 1, (B(sum, 0) << 8) | B(sum, 3));
+        if (sum & 3) s.put(U + 20 + (sum & 3), 1);
         if (F(F_JALR)) {
             s.put(U + 8, sum & 1);
             // link value a = pc + 4: its top byte is below 0x78 (comparator slot: u[19] = 1 = "u[10] < u[20]")
@@ -385,8 +386,6 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
             else if (F(F_SB)) m_val = (r.m_prev & ~(0xffu << sh8)) | ((c & 0xffu) << sh8);
             else if (F(F_SH)) m_val = (r.m_prev & ~(0xffffu << sh8)) | ((c & 0xffffu) << sh8);
             mem_port(m_val);
-            s.byte(B_AND - 1, (B(sum, 0) << 8) | 3);
-            if (o) s.put(U + 20 + o, 1);  // u[21..23]: one-hot of offsets 1..3
             if (F(F_LB) | F(F_LH)) {
                 const uint32_t sbyte = F(F_LB) ? B(a, 0) : B(a, 1);
                 s.put(U + 24, sbyte);

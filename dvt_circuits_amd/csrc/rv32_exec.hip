@@ -550,6 +550,7 @@ void build_prep(const Program &prog, HostPrep *out) {
         B0[(size_t)RV32_BYTE_P_and * nb + r] = b & c; B0[(size_t)RV32_BYTE_P_or * nb + r] = b | c;
         B0[(size_t)RV32_BYTE_P_xor * nb + r] = b ^ c; B0[(size_t)RV32_BYTE_P_ltu * nb + r] = b < c;
         B0[(size_t)RV32_BYTE_P_msb * nb + r] = b >> 7;
+        B0[(size_t)RV32_BYTE_P_addr * nb + r] = (b & 3) + 4 * (c >= (ADDR_LIMIT >> 24));
     }
     // memory image
     uint32_t li = ceil_log2(prog.image.size());
@@ -766,7 +767,7 @@ bool build_aux_host(const ShardMeta &S, const std::vector<AluEvent> &alu, const 
     T.log_n[RV32_CHIP_PROGRAM] = lp;
     T.main[RV32_CHIP_PROGRAM].assign((size_t)1 << lp, 0);
     T.log_n[RV32_CHIP_BYTE] = 16;
-    T.main[RV32_CHIP_BYTE] = byte_mult;  // [7][65536] already column-major in op order
+    T.main[RV32_CHIP_BYTE] = byte_mult;  // [N_BYTE_OPS][65536] already column-major in op order
     T.log_n[RV32_CHIP_MEM_IMAGE] = prep.log_n[RV32_CHIP_MEM_IMAGE];
     T.main[RV32_CHIP_MEM_IMAGE].assign((size_t)1 << T.log_n[RV32_CHIP_MEM_IMAGE], 0);
     T.pubs = {S.start_pc % P, S.next_pc % P, last ? (uint32_t)exit_code % P : 0u, S.index, last ? 1u : 0u};

@@ -19,7 +19,7 @@ import numpy as np
 P = 2013265921
 M32 = 0xFFFFFFFF
 ADDR_LIMIT = 0x38000000
-B_AND, B_OR, B_XOR, B_LTU, B_MSB, B_RANGE, B_U16 = 1, 2, 3, 4, 5, 6, 7
+B_AND, B_OR, B_XOR, B_LTU, B_MSB, B_RANGE, B_U16, B_ADDR = 1, 2, 3, 4, 5, 6, 7, 8
 ALU_CODES = dict(sll=1, srl=2, sra=3, mulh=4, mulhsu=5, div=6, divu=7, rem=8, remu=9)
 
 
@@ -375,7 +375,7 @@ def byts(w):
 
 class Lookups:
     def __init__(self):
-        self.byte = np.zeros((7, 65536), np.int64)
+        self.byte = np.zeros((8, 65536), np.int64)
 
     def add(self, op, b, c=0):
         self.byte[op - 1, (b << 8) | c if op != B_U16 else b] += 1
@@ -503,7 +503,7 @@ def traces(run: Run, pos: int):
             U[4:11] = carries[:7]
             for v in carries[:7]:
                 lk.add(B_U16, v)
-            lk.add(B_RANGE, other[0], other[1]); lk.add(B_RANGE, other[2], other[3])
+            lk.add(B_RANGE, other[1], other[2]); lk.add(B_RANGE, other[0], other[3])     # (the address adder's two lookups)
         elif k in ("lw", "sw", "lb", "lbu", "lh", "lhu", "sb", "sh", "jalr"):
             total, cy = (b + ins.off) & M32, 0
             for i in range(4):
@@ -511,17 +511,16 @@ def traces(run: Run, pos: int):
                 U[i], cy = t & 0xFF, t >> 8
                 U[4 + i] = cy
             s = byts(total)
-            lk.add(B_RANGE, s[0], s[1]); lk.add(B_RANGE, s[2], s[3]); lk.add(B_LTU, s[3], ADDR_LIMIT >> 24)
+            # byte ranges of the sum, top byte below 0x38 and byte offset s0 & 3 (one-hot in u[21..23]) in two lookups
+            lk.add(B_RANGE, s[1], s[2]); lk.add(B_ADDR, s[0], s[3])
+            if total & 3:
+                U[20 + (total & 3)] = 1
             if k == "jalr":
                 U[8] = total & 1
                 U[19], U[10], U[20] = 1, byts(a)[3], 0x78          # the link value's top byte is below 0x78 (comparator slot)
                 lk.add(B_LTU, byts(a)[3], 0x78)
             else:
                 mem_port(row.m_prev, row.m_val, row.mem)
-                lk.add(B_AND, s[0], 3)
-                o = total & 3
-                if o:
-                    U[20 + o] = 1
                 if k in ("lb", "lh"):
                     sb = byts(a)[0] if k == "lb" else byts(a)[1]
                     U[24], U[25] = sb, sb >> 7
@@ -712,7 +711,8 @@ def traces(run: Run, pos: int):
     bprep = np.zeros((chipb.prep_width, 65536), np.int64)
     rr = np.arange(65536)
     bb, cc = rr >> 8, rr & 255
-    for nm, v in (("b", bb), ("c", cc), ("and", bb & cc), ("or", bb | cc), ("xor", bb ^ cc), ("ltu", (bb < cc).astype(np.int64)), ("msb", bb >> 7)):
+    for nm, v in (("b", bb), ("c", cc), ("and", bb & cc), ("or", bb | cc), ("xor", bb ^ cc), ("ltu", (bb < cc).astype(np.int64)), ("msb", bb >> 7),
+                  ("addr", (bb & 3) + 4 * (cc >= (ADDR_LIMIT >> 24)).astype(np.int64))):
         bprep[chipb.prep_names.index(nm)] = v
     out["byte"] = (lk.byte, bprep)
     cidi, chipi = chips["mem_image"]

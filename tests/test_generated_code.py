@@ -22,12 +22,13 @@ def test_air_code_is_up_to_date():
 
 
 def test_cpu_chip_shape():
-    """the numbers DESIGN.md quotes: 96 main columns = 12 sponge blocks exactly, 30 interactions = 64 permutation columns"""
+    """the numbers DESIGN.md quotes: 96 main columns = 12 sponge blocks exactly, 28 interactions = 14 batches = 13 batch
+    columns + phi = 56 permutation columns = 7 sponge blocks exactly"""
     from tools.airgen import rv32
 
     cpu = next(c for c in rv32.build().chips if c.name == "cpu")
-    assert cpu.main_width == 96 and cpu.main_width % 8 == 0 and len(cpu.interactions) == 30
-    assert 4 * ((len(cpu.interactions) + 1) // 2 + 1) == 64
+    assert cpu.main_width == 96 and cpu.main_width % 8 == 0 and len(cpu.interactions) == 28
+    assert 4 * ((len(cpu.interactions) + 1) // 2) == 56
 
 
 def test_poseidon2_constants_are_up_to_date(tmp_path):

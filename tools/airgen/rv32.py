@@ -39,7 +39,10 @@ SYS_HINT_LEN = 0xF0
 REG_A1 = 11
 
 # byte-table opcodes
-B_AND, B_OR, B_XOR, B_LTU, B_MSB, B_RANGE, B_U16 = 1, 2, 3, 4, 5, 6, 7
+B_AND, B_OR, B_XOR, B_LTU, B_MSB, B_RANGE, B_U16, B_ADDR = 1, 2, 3, 4, 5, 6, 7, 8
+# B_ADDR [8, r, b, c]: r = (b & 3) + 4 * (c >= ADDR_TOP_BYTE).  A sender that puts a value 0..3 into r gets, in ONE lookup,
+# the byte offset b & 3 of an address whose low byte is b, the bound c < ADDR_TOP_BYTE on its top byte, and the range
+# check of both bytes.
 
 FLAGS = [
     "rd_en", "rs1_en", "rs2_en", "imm_c",
@@ -83,7 +86,8 @@ def build_byte():
     ch = Chip("byte")
     b, c = ch.prep("b"), ch.prep("c")
     r_and, r_or, r_xor, r_ltu, r_msb = ch.prep("and"), ch.prep("or"), ch.prep("xor"), ch.prep("ltu"), ch.prep("msb")
-    m = {k: ch.col("mult_" + k) for k in ("and", "or", "xor", "ltu", "msb", "range", "u16")}
+    r_addr = ch.prep("addr")
+    m = {k: ch.col("mult_" + k) for k in ("and", "or", "xor", "ltu", "msb", "range", "u16", "addr")}
     ch.receive("byte", [B_AND, r_and, b, c], m["and"])
     ch.receive("byte", [B_OR, r_or, b, c], m["or"])
     ch.receive("byte", [B_XOR, r_xor, b, c], m["xor"])
@@ -91,6 +95,7 @@ def build_byte():
     ch.receive("byte", [B_MSB, r_msb, b, c], m["msb"])      # senders use c = 0
     ch.receive("byte", [B_RANGE, 0, b, c], m["range"])
     ch.receive("byte", [B_U16, 0, 256 * b + c, 0], m["u16"])
+    ch.receive("byte", [B_ADDR, r_addr, b, c], m["addr"])
     return ch
 
 
@@ -271,9 +276,13 @@ def build_cpu():
         cin = acy[i - 1] if i else Expr.const(0)
         ch.assert_zero(sel_adder * (b[i] + off[i] + cin - s[i] - 256 * acy[i]))
         ch.assert_zero(sel_adder * (acy[i] * (acy[i] - 1)))
-    ch.send("byte", [B_RANGE, 0, s[0], s[1]], sel_adder + sel_mul)      # (MUL / MULHU: the bytes of x)
-    ch.send("byte", [B_RANGE, 0, s[2], s[3]], sel_adder + sel_mul)
-    ch.send("byte", [B_LTU, 1, s[3], ADDR_TOP_BYTE], sel_adder)        # address / target < 0x38000000
+    # range of the four sum bytes, address / target < 0x38000000, and the byte offset (low two address bits) in TWO lookups:
+    # [RANGE, 0, s1, s2] and [ADDR, offset, s0, s3] (byte-table op B_ADDR).  `offset` = o1 + 2 o2 + 3 o3 of the memory family
+    # below; on JALR rows those cells are free witnesses (the lookup makes them s0 & 3, nothing reads them); on MUL / MULHU
+    # rows (the bytes of x, plain range checks) the entry must be 0 and the cells are.
+    o_val = U[21] + 2 * U[22] + 3 * U[23]
+    ch.send("byte", [B_RANGE, 0, s[1], s[2]], sel_adder + sel_mul)
+    ch.send("byte", [B_ADDR * sel_adder + B_RANGE * sel_mul, o_val, s[0], s[3]], sel_adder + sel_mul)
     # JALR: u[8] = low bit cleared from the target
     jl = U[8]
     ch.assert_zero(F["is_jalr"] * (jl * (jl - 1)))
@@ -286,11 +295,10 @@ def build_cpu():
     o1, o2, o3, sb, sgn = U[21], U[22], U[23], U[24], U[25]
     o0 = 1 - o1 - o2 - o3
     oh = [o0, o1, o2, o3]
-    o_val = o1 + 2 * o2 + 3 * o3
     for x in (o1, o2, o3):
         ch.assert_zero(sel_mem * (x * (x - 1)))
     ch.assert_zero(sel_mem * ((o1 + o2 + o3) * (o1 + o2 + o3 - 1)))
-    ch.send("byte", [B_AND, o_val, s[0], 3], sel_mem)         # offset = low two address bits
+    # (offset = the low two address bits: the B_ADDR lookup above)
     ch.assert_zero((F["is_lw"] + F["is_sw"]) * (o1 + o2 + o3))                      # word access: aligned
     ch.assert_zero((F["is_lh"] + F["is_lhu"] + F["is_sh"]) * (o1 + o3))              # halfword access: even
     maddr = word(s) - o_val
