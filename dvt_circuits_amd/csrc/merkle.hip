@@ -30,19 +30,14 @@ __device__ __forceinline__ void hash_row(const uint32_t *const *cols, uint32_t n
     uint32_t w[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) w[k] = (uint32_t)k < ncols ? cols[k][row] : 0u;
-    uint32_t g = 0;
-    for (; g + 8 <= ncols; g += 8) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) s[k] = p2f::from_mont(w[k]);
-#pragma unroll
-        for (int k = 0; k < 8; k++) w[k] = g + 8 + k < ncols ? cols[g + 8 + k][row] : 0u;
-        p2f::permute(s);
-    }
-    const uint32_t rem = ncols - g;
-    if (rem) {
+    // ONE inlined copy of the permutation per kernel (~40 KB of straight-line code): a second copy for the ragged last
+    // block would put the loop beyond the 64 KB instruction cache.  The last block absorbs `ncols - g` < 8 words.
+    for (uint32_t g = 0; g < ncols; g += 8) {
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            if ((uint32_t)k < rem) s[k] = p2f::from_mont(w[k]);
+            if (g + k < ncols) s[k] = p2f::from_mont(w[k]);      // (wave-uniform condition)
+#pragma unroll
+        for (int k = 0; k < 8; k++) w[k] = g + 8 + k < ncols ? cols[g + 8 + k][row] : 0u;
         p2f::permute(s);
     }
 }
@@ -72,6 +67,8 @@ __global__ void __launch_bounds__(256) merkle_leaves_kernel(const uint32_t *cons
     store_digest(out, row, s);
 }
 
+// INJECT = false: the big levels of a tree (no shorter matrix joins there) - one permutation, one inlined copy of it.
+template <bool INJECT>
 __global__ void __launch_bounds__(256) merkle_level_kernel(const uint32_t *prev, const uint32_t *const *cols,
                                                           uint32_t ncols, size_t len, uint32_t *out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -80,7 +77,7 @@ __global__ void __launch_bounds__(256) merkle_level_kernel(const uint32_t *prev,
     double s[16];
     load_children(prev, i, len, s);
     p2f::permute(s);
-    if (ncols) {
+    if constexpr (INJECT) {
         double h[16];
         hash_row(cols, ncols, i, h);
 #pragma unroll
@@ -180,7 +177,8 @@ hipError_t launch_merkle_level(hipStream_t st, const uint32_t *d_prev, const uin
         return hipGetLastError();
     }
     unsigned blocks = (unsigned)((len + 255) / 256);
-    merkle_level_kernel<<<blocks, 256, 0, st>>>(d_prev, d_cols, ncols, len, d_out);
+    if (ncols) merkle_level_kernel<true><<<blocks, 256, 0, st>>>(d_prev, d_cols, ncols, len, d_out);
+    else merkle_level_kernel<false><<<blocks, 256, 0, st>>>(d_prev, d_cols, ncols, len, d_out);
     return hipGetLastError();
 }
 

@@ -50,35 +50,35 @@ DVT_HD void p2_external_layer(Fp s[16]) {
     }
 }
 
-// x / 2^k for 1 <= k <= 27, on residues (identical in Montgomery form): with x = hi * 2^k + lo,
-// x / 2^k = hi + lo * 2^-k and 2^-k = -15 * 2^(27-k) (mod p) because 15 * 2^27 = p - 1; lo * 15 * 2^(27-k) < p,
-// so the whole thing is a few shifts, one multiply-by-15 and one modular subtraction — no Montgomery product.
+// K x for a small literal K (the internal diagonal): doublings and additions, no Montgomery product
 template <int K>
-DVT_HD Fp p2_div_2exp(Fp x) {
-    const uint32_t lo = x.v & ((1u << K) - 1), hi = x.v >> K;
-    return Fp::raw(hi) - Fp::raw(((lo << 4) - lo) << (27 - K));
+DVT_HD Fp p2_mul_small(Fp x) {
+    if constexpr (K < 0) return -p2_mul_small<-K>(x);
+    else if constexpr (K == 1) return x;
+    else if constexpr (K % 2 == 0) return dbl(p2_mul_small<K / 2>(x));
+    else return dbl(p2_mul_small<K / 2>(x)) + x;
 }
-// y_i = sum(x) + d_i x_i with d = [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 1/2^8, 1/4, 1/8, 1/2^27, -1/2^8, -1/16, -1/2^27]
+// y_i = sum(x) + d_i x_i with d = [-2, 1, 2, 3, 4, -3, -4, 5, -5, 6, -6, 7, 8, -8, 9, -1] (tools/gen_poseidon2_rc.py)
 DVT_HD void p2_internal_layer(Fp s[16]) {
     Fp sum = s[0];
 #pragma unroll
     for (int i = 1; i < 16; i++) sum += s[i];
-    s[0] = sum - dbl(s[0]);
+    s[0] = sum + p2_mul_small<-2>(s[0]);
     s[1] = sum + s[1];
-    s[2] = sum + dbl(s[2]);
-    s[3] = sum + p2_div_2exp<1>(s[3]);
-    s[4] = sum + (dbl(s[4]) + s[4]);
-    s[5] = sum + dbl(dbl(s[5]));
-    s[6] = sum - p2_div_2exp<1>(s[6]);
-    s[7] = sum - (dbl(s[7]) + s[7]);
-    s[8] = sum - dbl(dbl(s[8]));
-    s[9] = sum + p2_div_2exp<8>(s[9]);
-    s[10] = sum + p2_div_2exp<2>(s[10]);
-    s[11] = sum + p2_div_2exp<3>(s[11]);
-    s[12] = sum + p2_div_2exp<27>(s[12]);
-    s[13] = sum - p2_div_2exp<8>(s[13]);
-    s[14] = sum - p2_div_2exp<4>(s[14]);
-    s[15] = sum - p2_div_2exp<27>(s[15]);
+    s[2] = sum + p2_mul_small<2>(s[2]);
+    s[3] = sum + p2_mul_small<3>(s[3]);
+    s[4] = sum + p2_mul_small<4>(s[4]);
+    s[5] = sum + p2_mul_small<-3>(s[5]);
+    s[6] = sum + p2_mul_small<-4>(s[6]);
+    s[7] = sum + p2_mul_small<5>(s[7]);
+    s[8] = sum + p2_mul_small<-5>(s[8]);
+    s[9] = sum + p2_mul_small<6>(s[9]);
+    s[10] = sum + p2_mul_small<-6>(s[10]);
+    s[11] = sum + p2_mul_small<7>(s[11]);
+    s[12] = sum + p2_mul_small<8>(s[12]);
+    s[13] = sum + p2_mul_small<-8>(s[13]);
+    s[14] = sum + p2_mul_small<9>(s[14]);
+    s[15] = sum + p2_mul_small<-1>(s[15]);
 }
 
 DVT_HD void p2_permute(Fp s[16]) {

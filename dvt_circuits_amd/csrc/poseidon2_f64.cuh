@@ -37,24 +37,16 @@ DVT_F64_TABLE double DIAG[16] = DVT_P2_DIAG_F64_INIT;
 
 constexpr double PD = 2013265921.0;
 constexpr double PINV = 1.0 / 2013265921.0;
-constexpr double MAGIC = 6755399441055744.0;  // 1.5 * 2^52: (x + MAGIC) - MAGIC = x rounded to an integer, |x| < 2^51
 constexpr double MONT_R = 268435454.0;        // 2^32 mod p
 constexpr double MONT_RINV = 943718400.0;     // 2^-32 mod p
 
-DVT_DEV double rnd(double x) { return (x + MAGIC) - MAGIC; }
+// round to nearest even: v_rndne_f64 (measured 1.5 % faster per permutation than the (x + 1.5 * 2^52) - 1.5 * 2^52 pair)
+DVT_DEV double rnd(double x) { return __builtin_rint(x); }
 DVT_DEV double mm(double a, double b) {
     double h = a * b;
     double l = fma(a, b, -h);
     double q = rnd(h * PINV);
     return fma(-q, PD, h) + l;
-}
-// a * c for c = +-15 * 2^m (every fractional entry of the internal diagonal: 2^-k = -15 * 2^(27-k), 1/2 = -15 * 2^26):
-// 15 a is exact for |a| < 2^49 and the power of two only moves the exponent, so ONE multiplication gives the exact
-// product and no error term is needed: 4 operations instead of 6.  |a| < 2^48 (quotient < 2^51).
-DVT_DEV double mm_exact_const(double a, double c) {
-    double h = a * c;
-    double q = rnd(h * PINV);
-    return fma(-q, PD, h);
 }
 // |a| < 2^51  ->  the representative in [-p/2, p/2] (+- a rounding slack far below 1 for |a| < 2^48)
 DVT_DEV double red(double a) { return fma(-rnd(a * PINV), PD, a); }
@@ -102,8 +94,8 @@ DVT_DEV void external_layer(double s[16]) {
     }
 }
 
-// y_i = sum + d_i x_i, d = [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 2^-8, 1/4, 1/8, 2^-27, -2^-8, -1/16, -2^-27] (poseidon2.cuh);
-// as centred residues 2^-27 = -15, 2^-k = -15 * 2^(27-k), 1/2 = -(p-1)/2.  max |s| = B (< 2^48) -> <= 31 B.
+// y_i = sum + d_i x_i, d = [-2, 1, 2, 3, 4, -3, -4, 5, -5, 6, -6, 7, 8, -8, 9, -1] (tools/gen_poseidon2_rc.py): one fused
+// multiply-add per entry, exact.  max |s| = B (< 2^48) -> <= 25 B.
 template <bool REDUCE>
 DVT_DEV void internal_layer(double s[16]) {
     if (REDUCE) {
@@ -116,26 +108,26 @@ DVT_DEV void internal_layer(double s[16]) {
     s[0] = fma(-2.0, s[0], sum);
     s[1] = sum + s[1];
     s[2] = fma(2.0, s[2], sum);
-    s[3] = sum + mm_exact_const(s[3], -1006632960.0);
-    s[4] = fma(3.0, s[4], sum);
-    s[5] = fma(4.0, s[5], sum);
-    s[6] = sum + mm_exact_const(s[6], 1006632960.0);
-    s[7] = fma(-3.0, s[7], sum);
-    s[8] = fma(-4.0, s[8], sum);
-    s[9] = sum + mm_exact_const(s[9], -7864320.0);
-    s[10] = sum + mm_exact_const(s[10], -503316480.0);
-    s[11] = sum + mm_exact_const(s[11], -251658240.0);
-    s[12] = fma(-15.0, s[12], sum);
-    s[13] = sum + mm_exact_const(s[13], 7864320.0);
-    s[14] = sum + mm_exact_const(s[14], 125829120.0);
-    s[15] = fma(15.0, s[15], sum);
+    s[3] = fma(3.0, s[3], sum);
+    s[4] = fma(4.0, s[4], sum);
+    s[5] = fma(-3.0, s[5], sum);
+    s[6] = fma(-4.0, s[6], sum);
+    s[7] = fma(5.0, s[7], sum);
+    s[8] = fma(-5.0, s[8], sum);
+    s[9] = fma(6.0, s[9], sum);
+    s[10] = fma(-6.0, s[10], sum);
+    s[11] = fma(7.0, s[11], sum);
+    s[12] = fma(8.0, s[12], sum);
+    s[13] = fma(-8.0, s[13], sum);
+    s[14] = fma(9.0, s[14], sum);
+    s[15] = sum - s[15];
 }
 
 // in: |s_i| < 2^32 (canonical words, from_mont results or a previous output); out: |s_i| < 0.51 p.
 // Magnitudes: after an S-box layer every entry is below 0.51 p (2^30.03), the external layer multiplies the bound
 // by 35 (2^35.2, the S-box input bound with a round constant added); in the internal rounds s[0] is reduced before
-// each S-box and the other entries every third round: 2^35.2 -> x31 -> 2^40.2 -> 2^45.1 -> reduce, and from a
-// reduced state 2^30 -> 2^35 -> 2^40 -> 2^45 (< 2^48 as the sums and the products with |d| < 2^30 need).
+// each S-box and the other entries every third round: 2^35.2 -> x25 -> 2^39.8 -> 2^44.5 -> reduce, and from a
+// reduced state 2^30 -> 2^34.7 -> 2^39.3 -> 2^44 (< 2^48 as the sums need).
 DVT_DEV void permute(double s[16]) {
     external_layer(s);
 #pragma unroll
@@ -215,8 +207,8 @@ __device__ __forceinline__ double coop_permute(double s, const CoopConsts &k) {
         t = t + dpp_mov<DPP_ROW_ROR + 4>(t);
         t = t + dpp_mov<DPP_ROW_ROR + 2>(t);
         t = t + dpp_mov<DPP_ROW_ROR + 1>(t);
-        // every diagonal entry is a small integer or +-15 * 2^m and s is reduced: s * diag is exact in one multiplication
-        s = red(t + mm_exact_const(s, k.diag));          // every entry stays reduced: |sum| <= 16 * 0.51 p
+        // every diagonal entry is a small integer and s is reduced: the fused multiply-add is exact
+        s = red(fma(s, k.diag, t));                      // every entry stays reduced: |sum| <= 16 * 0.51 p
     }
 #pragma unroll
     for (int r = 4; r < 8; r++) s = coop_external_layer(sbox(s + k.rc[r]));

@@ -7,10 +7,11 @@
  *   external layer: M4 = circ(2,3,1,1) on every 4-chunk, then add the column
  *                   sums (Poseidon2 paper, section 5.1)
  *   internal layer: y_i = diag_i * x_i + sum(x),
- *                   diag = [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 1/2^8, 1/4, 1/8, 1/2^27, -1/2^8, -1/16, -1/2^27]
- *                   (the small-integer / inverse-power-of-two diagonal published for BabyBear width 16 by
- *                   Plonky3; on gfx950 every entry is a handful of shifts and adds because
- *                   2^-k = -15 * 2^(27-k) mod p — the HIP path exploits that, this file just multiplies)
+ *                   diag = [-2, 1, 2, 3, 4, -3, -4, 5, -5, 6, -6, 7, 8, -8, 9, -1]
+ *                   (sixteen distinct small integers: one fused multiply-add each on the FP64 pipe of gfx950, this
+ *                   file just multiplies.  NOT the Plonky3 BabyBear diagonal [-2, 1, 2, 1/2, 3, 4, -1/2, ...]: the
+ *                   set is validated with the Poseidon2 paper's condition on the internal matrix by
+ *                   tools/check_poseidon2_diag.py, which the tests run)
  * The stock round-constant table (RC_16_30_U32, 480 words) is not in the
  * container, so the constants are derived here:
  *   block_i  = SHA-256("dvt-amd/poseidon2-babybear-w16/rc" || LE32(i))
@@ -51,9 +52,8 @@ __attribute__((constructor)) static void init_constants(void) {
         for (int j = 0; j < 16; j++) RC_EXT[r][j] = all[r * 16 + j];
     for (int r = 0; r < N_INT; r++) RC_INT[r] = all[N_EXT * 16 + r];
     {
-        bb_t i2 = bb_inv(2), i4 = bb_inv(4), i8 = bb_inv(8), i16 = bb_inv(16), i256 = bb_inv(256), i27 = bb_inv(1u << 27);
-        bb_t d[16] = {BB_P - 2, 1, 2, i2, 3, 4, bb_neg(i2), BB_P - 3, BB_P - 4, i256, i4, i8, i27, bb_neg(i256), bb_neg(i16), bb_neg(i27)};
-        memcpy(DIAG, d, sizeof d);
+        static const int small[16] = {-2, 1, 2, 3, 4, -3, -4, 5, -5, 6, -6, 7, 8, -8, 9, -1};
+        for (int i = 0; i < 16; i++) DIAG[i] = small[i] < 0 ? BB_P - (bb_t)(-small[i]) : (bb_t)small[i];
     }
     inited = 1;
 }

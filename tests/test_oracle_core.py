@@ -21,8 +21,7 @@ def py_constants():
         i += 1
     ext = [out[r * 16 : (r + 1) * 16] for r in range(8)]
     internal = out[128 : 128 + 13]
-    inv = lambda x: pow(x, P - 2, P)
-    diag = [P - 2, 1, 2, inv(2), 3, 4, P - inv(2), P - 3, P - 4, inv(256), inv(4), inv(8), inv(1 << 27), P - inv(256), P - inv(16), P - inv(1 << 27)]
+    diag = [d % P for d in (-2, 1, 2, 3, 4, -3, -4, 5, -5, 6, -6, 7, 8, -8, 9, -1)]
     return ext, internal, diag
 
 
@@ -71,6 +70,24 @@ def test_poseidon2_constants_derivation(oracle):
     assert i.tolist() == pi
     assert d.tolist() == pd
     assert all(x < P for x in e.tolist() + i.tolist())
+
+
+def test_internal_diagonal_satisfies_the_poseidon2_condition():
+    """the product's small-integer internal diagonal (and, as a control of the checker, Plonky3's BabyBear-16 one) passes
+    the Poseidon2 paper's test: the characteristic polynomial of M_I^i is irreducible for i = 1 .. 32; a diagonal with a
+    repeated entry does not"""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import check_poseidon2_diag as chk
+    import gen_poseidon2_rc
+
+    assert sorted(gen_poseidon2_rc.INTERNAL_DIAG) == [-8, -6, -5, -4, -3, -2, -1, 1, 2, 3, 4, 5, 6, 7, 8, 9]
+    assert py_constants()[2] == [d % P for d in gen_poseidon2_rc.INTERNAL_DIAG]
+    assert chk.check(gen_poseidon2_rc.INTERNAL_DIAG)
+    assert chk.check(chk.PLONKY3)
+    assert not chk.check([1, 1] + list(range(2, 16)))
 
 
 def test_poseidon2_permute_matches_python(oracle):
