@@ -533,13 +533,10 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
         HIPCHK(s.d->launch_perm(stream, pa));
         ALLOC(scan_scratch, uint32_t, prefix_sum_scratch_words(4, s.n));
         HIPCHK(launch_prefix_sum_columns(stream, totals, 4, s.n, scan_scratch));
-        HIPCHK(launch_phi_from_prefix_sums(stream, totals, s.perm + (bw - 4) * s.n, s.log_n));
-        const uint32_t *phi = totals;   // (the cumulative sum = the last inclusive prefix sum)
-        // the cumulative sum is only needed for the transcript, after the permutation tree: its four words are copied
-        // asynchronously into the tail of the pinned staging buffer and read after the next synchronisation
+        // the cumulative sum is only needed for the transcript, after the permutation tree: the kernel writes its four
+        // words into the tail of the pinned staging buffer, read after the next synchronisation
         uint32_t *cw = reinterpret_cast<uint32_t *>(h_down + DOWN_BYTES - 4096) + 4 * n_cumsum++;
-        for (int k = 0; k < 4; k++)
-            HIPCHK(hipMemcpyAsync(&cw[k], phi + (size_t)k * s.n + s.n - 1, 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(launch_phi_from_prefix_sums(stream, totals, s.perm + (bw - 4) * s.n, s.log_n, cw));
         HIPCHK(lde(s.perm, d_scratch, s.perm_lde, (uint32_t)bw, s.log_n, 0));
         mats.push_back({s.perm_lde, (uint32_t)bw, s.log_n + 1});
         perm_hmax = std::max(perm_hmax, s.log_n + 1);

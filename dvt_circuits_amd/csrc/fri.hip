@@ -79,9 +79,13 @@ hipError_t launch_prefix_sum_columns(hipStream_t st, uint32_t *d_cols, uint32_t 
 }
 size_t prefix_sum_scratch_words(uint32_t ncols, size_t n) { return ncols * ((n + SCAN_BLOCK - 1) / SCAN_BLOCK); }
 
-__global__ void __launch_bounds__(256) phi_from_prefix_sums_kernel(const uint32_t *tot, uint32_t *phi, size_t n, Fp n_inv) {
+__global__ void __launch_bounds__(256) phi_from_prefix_sums_kernel(const uint32_t *tot, uint32_t *phi, size_t n, Fp n_inv, uint32_t *cum_out) {
     size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
+    if (r == n - 1 && cum_out) {   // the cumulative sum, straight into the caller's (pinned host) buffer: no copy commands
+#pragma unroll
+        for (int k = 0; k < 4; k++) cum_out[k] = tot[(size_t)k * n + n - 1];
+    }
     const Fp rf = Fp::from_canonical((uint32_t)r) * n_inv;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -90,9 +94,9 @@ __global__ void __launch_bounds__(256) phi_from_prefix_sums_kernel(const uint32_
         phi[(size_t)k * n + r] = (before - c).v;
     }
 }
-hipError_t launch_phi_from_prefix_sums(hipStream_t st, const uint32_t *d_totals, uint32_t *d_phi, uint32_t log_n) {
+hipError_t launch_phi_from_prefix_sums(hipStream_t st, const uint32_t *d_totals, uint32_t *d_phi, uint32_t log_n, uint32_t *cum_out) {
     const size_t n = (size_t)1 << log_n;
-    phi_from_prefix_sums_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_totals, d_phi, n, inv(Fp::from_canonical((uint32_t)n)));
+    phi_from_prefix_sums_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_totals, d_phi, n, inv(Fp::from_canonical((uint32_t)n)), cum_out);
     return hipGetLastError();
 }
 

@@ -57,8 +57,9 @@ hipError_t launch_poseidon2_permute(hipStream_t st, uint32_t *d_states, size_t n
 hipError_t launch_prefix_sum_columns(hipStream_t st, uint32_t *d_cols, uint32_t ncols, size_t n, uint32_t *d_scratch);
 size_t prefix_sum_scratch_words(uint32_t ncols, size_t n);
 // K4 tail: d_totals = inclusive prefix sums S of the row totals ([4][n], one F_p^4 per row); writes the running-sum
-// column phi[r] = S[r-1] - r * S[n-1] / n  (phi[0] = 0) of the folded LogUp layout (stark.cuh) into d_phi ([4][n])
-hipError_t launch_phi_from_prefix_sums(hipStream_t st, const uint32_t *d_totals, uint32_t *d_phi, uint32_t log_n);
+// column phi[r] = S[r-1] - r * S[n-1] / n  (phi[0] = 0) of the folded LogUp layout (stark.cuh) into d_phi ([4][n]) and,
+// with cum_out != nullptr, the four words of S[n-1] to cum_out (device-accessible memory, e.g. pinned host memory)
+hipError_t launch_phi_from_prefix_sums(hipStream_t st, const uint32_t *d_totals, uint32_t *d_phi, uint32_t log_n, uint32_t *cum_out);
 hipError_t launch_open_weights(hipStream_t st, const NttTables &tabs, Fp4 z, uint32_t log_n, Fp4 *d_w);
 constexpr uint32_t OPEN_MAX_ROW_BLOCKS = 256;
 uint32_t open_row_blocks(uint32_t log_n);
