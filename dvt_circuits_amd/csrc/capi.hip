@@ -392,7 +392,7 @@ namespace {
 constexpr uint32_t CORE_PROOF_MAGIC = 0x33435644u;  // "DVC3"
 constexpr uint32_t N_PUB = rv32::N_PUBLIC;           // start_pc, next_pc, exit_code, shard, is_last
 constexpr uint32_t HEADER_WORDS = 8 + N_PUB;         // per-shard commitment header: main root + public values (canonical)
-constexpr uint32_t PV_BUS = 5;                       // tools/airgen/rv32.py BUSES["pv"]
+constexpr uint32_t PV_BUS = 5;                       // tools/airgen/rv32.py BUSES["sys"]
 
 std::vector<std::vector<uint8_t>> collect_stdin(const dvt_buf *bufs, size_t n) {
     std::vector<std::vector<uint8_t>> v(n);
@@ -674,7 +674,7 @@ static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_buf
                             ec = pl.exit_code;
                         }
                         std::string e;
-                        if (!pl.abort && !rv32::build_aux_host(r.meta, so.alu, rows, ec, pk->prep, &r.aux, &e)) r.err = e;
+                        if (!pl.abort && !rv32::build_aux_host(r.meta, so.alu, so.sha_ext, rows, ec, pk->prep, &r.aux, &e)) r.err = e;
                     }
                 }
                 std::lock_guard<std::mutex> lk(pl.mu);
@@ -1088,19 +1088,20 @@ int dvt_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, size_t pr
             if (!why.empty()) return reject(DVT_ERR_REJECTED, "shard " + std::to_string(i + 1) + ": " + why);
             total += t;
         }
-        // The receiving side of the public-values bus is supplied here, from the claimed bytes: an SP1 guest commits the
-        // eight words of SHA-256(public-value bytes) with COMMIT(k, word k); tuple k contributes
-        // 1 / (alpha + bus + beta k + beta^2 b0 + ... + beta^5 b3), b = the bytes of digest word k.
+        // The receiving side of the COMMIT rows' sys-bus tuples is supplied here, from the claimed bytes: an SP1 guest commits
+        // the eight words of SHA-256(public-value bytes) with COMMIT(k, word k); the cpu chip sends
+        // (t0 bytes = 0x10 0 0 0, a0 bytes = k 0 0 0, a1 bytes = the bytes of digest word k, 0, 0), tuple k contributes
+        // 1 / (alpha + bus + beta 0x10 + beta^5 k + beta^9 b0 + ... + beta^12 b3).
         {
             uint8_t dg[32];
             sha256(pv.data(), pv.size(), dg);
-            Fp4 bp[5];
-            bp[0] = gc.beta;
-            for (int k = 1; k < 5; k++) bp[k] = bp[k - 1] * gc.beta;
+            Fp4 bp[13];
+            bp[1] = gc.beta;
+            for (int k = 2; k < 13; k++) bp[k] = bp[k - 1] * gc.beta;
             Fp4 expect = Fp4::zero();
             for (uint32_t k = 0; k < 8; k++) {
-                Fp4 d = gc.alpha + Fp::from_canonical(PV_BUS) + bp[0] * Fp::from_canonical(k);
-                for (int b = 0; b < 4; b++) d += bp[1 + b] * Fp::from_canonical(dg[4 * k + b]);
+                Fp4 d = gc.alpha + Fp::from_canonical(PV_BUS) + bp[1] * Fp::from_canonical(rv32::SYS_COMMIT) + bp[5] * Fp::from_canonical(k);
+                for (int b = 0; b < 4; b++) d += bp[9 + b] * Fp::from_canonical(dg[4 * k + b]);
                 expect += inv(d);
             }
             if (total != expect) return reject(DVT_ERR_REJECTED, "LogUp cumulative sums do not cancel across the shards (memory bus or public-values digest)");

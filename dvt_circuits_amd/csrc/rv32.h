@@ -40,11 +40,12 @@ constexpr uint32_t B_AND = 1, B_OR = 2, B_XOR = 3, B_LTU = 4, B_MSB = 5, B_RANGE
 constexpr int N_BYTE_OPS = 8;  // multiplicity columns of the byte chip, in this order: and or xor ltu msb range u16 addr
 constexpr uint32_t ADDR_LIMIT = 0x38000000u;  // tools/airgen/rv32.py ADDR_TOP_BYTE: address + address gap stays below p
 constexpr uint32_t SYS_COMMIT = 0x10;
+constexpr uint32_t SYS_SHA_EXTEND = 0x00300105u;  // SP1 syscall code (byte 1 = 1: the call has a precompile table)
 constexpr uint32_t REG_A1 = 11;
 constexpr uint32_t MAX_SHARDS = 65535;        // shard numbers travel as 16-bit halves of the cycle records
 constexpr uint32_t ALU_SLL = 1, ALU_SRL = 2, ALU_SRA = 3;  // alu-bus opcodes (chips outside the cpu chip): shift chip
 constexpr uint32_t ALU_MULH = 4, ALU_MULHSU = 5, ALU_DIV = 6, ALU_DIVU = 7, ALU_REM = 8, ALU_REMU = 9;  // muldiv chip
-constexpr int N_CHIPS = 7;  // program, byte, cpu, mem_image, mem_init, shift, muldiv
+constexpr int N_CHIPS = 8;  // program, byte, cpu, mem_image, mem_init, shift, muldiv, sha_extend
 constexpr uint32_t N_PUBLIC = 5;  // start_pc, next_pc, exit_code, shard, is_last
 
 // dense dispatch code of the interpreter (one case per instruction form: which ports it drives is static per case)
@@ -122,10 +123,18 @@ struct MemInitRow {
 struct AluEvent {
     uint32_t op, a, b, c;
 };
+// one SHA_EXTEND call: w[0..15] as read, w[16..63] as written, the words those replaced, and the (shard, clk) each of the
+// 64 words carried before the call
+struct ShaExtEvent {
+    uint32_t clk, ptr;
+    uint32_t w[64], old[64], prev_ts[64];
+    uint16_t prev_sh[64];
+};
 
 // One shard = up to 2^log_shard consecutive cycles; shards are numbered from 1.
 struct ShardRec {
     std::vector<AluEvent> alu;   // instructions of this shard proven by chips outside the cpu chip
+    std::vector<ShaExtEvent> sha_ext;   // precompile calls of this shard
     uint32_t index = 0, start_pc = 0, next_pc = 0;
     std::vector<CycleRec> recs;
 };
@@ -179,6 +188,7 @@ struct ShardOut {
     CycleRec *recs = nullptr;
     size_t n_recs = 0;
     std::vector<AluEvent> alu;
+    std::vector<ShaExtEvent> sha_ext;
     uint32_t index = 0, start_pc = 0, next_pc = 0;
 };
 
@@ -398,18 +408,27 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
         s.byte(B_LTU - 1, (B(a, 3) << 8) | LINK_TOP_BYTE);
     } else if (F(F_ECALL)) {
         // u[4] is_halt, u[5] 1/id, u[6] is_commit, u[7] 1/(id - COMMIT), u[24] is HINT_LEN (the one call that returns a value
-        // in t0), u[25] 1/(id - HINT_LEN); COMMIT rows read a1 (x11) through the memory port
+        // in t0), u[25] 1/(id - HINT_LEN); u[1] is_pre (byte 1 of the code = 1: the call has a precompile chip), u[2] 1/(byte 1 - 1).
+        // COMMIT and precompile rows ("sys rows") read a1 (x11) through the memory port and send on the sys bus; u[3] / u[21] =
+        // clk / shard on precompile rows; u[0] balances the port's address expression u0 + 256 u1 + .. - (u21 + 2 u22 + 3 u23) = 11
         uint32_t idc = b % P;
         s.put(U + 24, idc == SYS_HINT_LEN);
         if (idc != SYS_HINT_LEN) s.put(U + 25, inv(Fp::from_canonical(idc) - Fp::from_canonical(SYS_HINT_LEN)).canonical());
         s.put(U + 4, idc == 0);
         if (idc) s.put(U + 5, inv(Fp::from_canonical(idc)).canonical());
-        const bool is_commit = idc == SYS_COMMIT;
+        const bool is_commit = idc == SYS_COMMIT, is_pre = B(b, 1) == 1;
         s.put(U + 6, is_commit);
         if (!is_commit) s.put(U + 7, inv(Fp::from_canonical(idc) - Fp::from_canonical(SYS_COMMIT)).canonical());
-        s.put(RV32_CPU_commit_m, is_commit);
-        if (is_commit) {
-            s.put(U + 0, REG_A1);
+        const uint32_t pre_inv = is_pre ? 0u : inv(Fp::from_canonical(B(b, 1)) - Fp::one()).canonical();
+        s.put(U + 1, is_pre); s.put(U + 2, pre_inv);
+        s.put(RV32_CPU_sys_m, is_commit || is_pre);
+        if (is_commit || is_pre) {
+            const uint32_t u_clk = is_pre ? clk : 0u, u_sh = is_pre ? shard : 0u;
+            s.put(U + 3, u_clk); s.put(U + 21, u_sh);
+            // the port's address expression u0 + 256 u1 + 65536 u2 + 2^24 u3 - (u21 + 2 u22 + 3 u23) must be 11
+            const Fp u0 = Fp::from_canonical(REG_A1) - Fp::from_canonical(256u * is_pre) - Fp::from_canonical(65536) * Fp::from_canonical(pre_inv) -
+                          Fp::from_canonical(1u << 24) * Fp::from_canonical(u_clk) + Fp::from_canonical(u_sh);
+            s.put(U + 0, u0.canonical());
             mem_port(r.m_prev);
         }
     }
@@ -442,8 +461,8 @@ struct ShardMeta {
     uint32_t index, start_pc, next_pc;
     size_t n_recs;
 };
-bool build_aux_host(const ShardMeta &meta, const std::vector<AluEvent> &alu, const std::vector<MemInitRow> *mem_rows, int exit_code,
-                    const HostPrep &prep, HostTraces *out, std::string *err);
+bool build_aux_host(const ShardMeta &meta, const std::vector<AluEvent> &alu, const std::vector<ShaExtEvent> &sha_ext,
+                    const std::vector<MemInitRow> *mem_rows, int exit_code, const HostPrep &prep, HostTraces *out, std::string *err);
 // the whole shard on the host, cpu chip included (debug C-ABI, tests)
 bool build_traces_host(const Program &prog, const ExecResult &res, size_t shard_pos, const HostPrep &prep, HostTraces *out, std::string *err);
 // instruction index -> row of the program table (provable instructions only; others map to row 0 and never occur)

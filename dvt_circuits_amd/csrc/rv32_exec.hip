@@ -243,6 +243,7 @@ void Vm::run_shard(bool trace, ShardOut *out, uint64_t max_total_cycles) {
         out->start_pc = pc;
         out->n_recs = 0;
         out->alu.clear();
+        out->sha_ext.clear();
         run<true>(out, budget);
         out->next_pc = pc;   // 0 after HALT
     } else {
@@ -394,6 +395,33 @@ L_ECALL: {
         if (c < 8) { committed[c] = a1; committed_mask |= 1u << c; }
         break;
     }
+    case SYS_SHA_EXTEND: {  // SHA_EXTEND(a0 = w): w[16..63] of the SHA-256 message schedule, in place (precompile chip sha_extend)
+        if (a1 != 0) { why = "SHA_EXTEND with a1 != 0"; goto trapped; }
+        if (c % 4 || c < 32 || (uint64_t)c + 256 > ADDR_LIMIT) { why = "SHA_EXTEND pointer misaligned or out of range"; goto trapped; }
+        {   // a1 (x11) is read through the memory port, as for COMMIT
+            Cell &r11 = regs[REG_A1];
+            if (TRACE) { rec.m_prev = r11.val; rec.m_ts = r11.ts(); shm = r11.sh(); }
+            r11.tsh = sh64 | (clk + 2);
+        }
+        ShaExtEvent *ev = nullptr;
+        if (TRACE) { out->sha_ext.emplace_back(); ev = &out->sha_ext.back(); ev->clk = clk; ev->ptr = c; }
+        uint32_t w[64];
+        for (uint32_t k = 0; k < 64; k++) {   // every word of the array is accessed exactly once, at (shard, clk + 2)
+            Cell &cell = at(c + 4 * k);
+            if (!(cell.flags & (FL_TOUCHED | FL_IMG))) { cell.flags |= FL_TOUCHED; if (collect_output) first_touch.emplace_back(c + 4 * k, cell.val); }
+            if (k < 16) w[k] = cell.val;
+            else {
+                const uint32_t x = w[k - 15], y = w[k - 2];
+                const uint32_t s0 = ((x >> 7) | (x << 25)) ^ ((x >> 18) | (x << 14)) ^ (x >> 3);
+                const uint32_t s1 = ((y >> 17) | (y << 15)) ^ ((y >> 19) | (y << 13)) ^ (y >> 10);
+                w[k] = s1 + w[k - 7] + s0 + w[k - 16];
+            }
+            if (TRACE) { ev->old[k] = cell.val; ev->prev_ts[k] = cell.ts(); ev->prev_sh[k] = (uint16_t)cell.sh(); ev->w[k] = w[k]; }
+            cell.val = w[k];
+            cell.tsh = sh64 | (clk + 2);
+        }
+        break;
+    }
     case 0x1a: break;  // COMMIT_DEFERRED_PROOFS: no-op (no recursion in core proofs)
     case 0xf0: a = next_input < stdin_bufs->size() ? (uint32_t)(*stdin_bufs)[next_input].size() : 0; break;
     case 0xf1: {  // HINT_READ(ptr = a0, len = a1): the words become initial memory (must be untouched so far)
@@ -495,6 +523,7 @@ void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin
             S.index = out.index; S.start_pc = out.start_pc; S.next_pc = out.next_pc;
             S.recs.assign(out.recs, out.recs + out.n_recs);
             S.alu = out.alu;
+            S.sha_ext = out.sha_ext;
         }
         if (vm.halted || !vm.error.empty()) break;
         if (!vm.next_shard()) break;
@@ -585,8 +614,8 @@ std::vector<uint32_t> program_row_map(const Program &prog) {
     return m;
 }
 
-bool build_aux_host(const ShardMeta &S, const std::vector<AluEvent> &alu, const std::vector<MemInitRow> *mem_rows, int exit_code,
-                    const HostPrep &prep, HostTraces *out, std::string *err) {
+bool build_aux_host(const ShardMeta &S, const std::vector<AluEvent> &alu, const std::vector<ShaExtEvent> &sha_ext,
+                    const std::vector<MemInitRow> *mem_rows, int exit_code, const HostPrep &prep, HostTraces *out, std::string *err) {
     HostTraces &T = *out;
     if (S.n_recs == 0) { if (err) *err = "no cycles to prove"; return false; }
     const bool last = mem_rows != nullptr;
@@ -763,6 +792,61 @@ bool build_aux_host(const ShardMeta &S, const std::vector<AluEvent> &alu, const 
             sink.byte(B_U16 - 1, dl0); sink.byte(B_U16 - 1, dl1);
         }
     }
+    // sha_extend chip: 64 rows per SHA_EXTEND call (absent when the shard makes none)
+    T.present[RV32_CHIP_SHA_EXTEND] = !sha_ext.empty();
+    T.log_n[RV32_CHIP_SHA_EXTEND] = 0;
+    if (!sha_ext.empty()) {
+        const uint32_t lx = ceil_log2(sha_ext.size() * 64);
+        const size_t nx = (size_t)1 << lx;
+        T.log_n[RV32_CHIP_SHA_EXTEND] = lx;
+        auto &H = T.main[RV32_CHIP_SHA_EXTEND];
+        H.assign((size_t)RV32_SHA_EXTEND_MAIN_W * nx, 0);
+        for (size_t e = 0; e < sha_ext.size(); e++) {
+            const ShaExtEvent &ev = sha_ext[e];
+            for (uint32_t j = 0; j < 64; j++) {
+                const size_t row = e * 64 + j;
+                auto put = [&](int col, uint32_t v) { H[(size_t)col * nx + row] = v; };
+                auto put_word = [&](int col0, uint32_t v) { for (int i = 0; i < 4; i++) put(col0 + i, (v >> (8 * i)) & 0xff); };
+                put(RV32_SHA_EXTEND_is_real, 1);
+                put(RV32_SHA_EXTEND_is_first, j == 0); put(RV32_SHA_EXTEND_is_last, j == 63);
+                put(RV32_SHA_EXTEND_is_load, j < 16); put(RV32_SHA_EXTEND_is_e, j == 15);
+                put(RV32_SHA_EXTEND_j, j);
+                if (j != 63) put(RV32_SHA_EXTEND_j_inv, inv(Fp::from_canonical(j) - Fp::from_canonical(63)).canonical());
+                put(RV32_SHA_EXTEND_clk, ev.clk);
+                put_word(RV32_SHA_EXTEND_p_0, ev.ptr);
+                // window: W[k] = w[j - 16 + k] (zero before the array's start)
+                for (uint32_t k = 0; k < 16; k++) put_word(RV32_SHA_EXTEND_w0_0 + 4 * k, j + k >= 16 ? ev.w[j + k - 16] : 0u);
+                const uint32_t x = j + 1 >= 16 ? ev.w[j + 1 - 16] : 0u, y = j + 14 >= 16 ? ev.w[j + 14 - 16] : 0u;
+                for (int k = 0; k < 32; k++) { put(RV32_SHA_EXTEND_xb_0 + k, (x >> k) & 1); put(RV32_SHA_EXTEND_yb_0 + k, (y >> k) & 1); }
+                const uint32_t s0 = ((x >> 7) | (x << 25)) ^ ((x >> 18) | (x << 14)) ^ (x >> 3);
+                const uint32_t s1 = ((y >> 17) | (y << 15)) ^ ((y >> 19) | (y << 13)) ^ (y >> 10);
+                put(RV32_SHA_EXTEND_s0_0, s0 & 0xffff); put(RV32_SHA_EXTEND_s0_1, s0 >> 16);
+                put(RV32_SHA_EXTEND_s1_0, s1 & 0xffff); put(RV32_SHA_EXTEND_s1_1, s1 >> 16);
+                const uint32_t nw = ev.w[j];
+                put_word(RV32_SHA_EXTEND_nw_0, nw);
+                put_word(RV32_SHA_EXTEND_old_0, ev.old[j]);
+                if (j >= 16) {
+                    const uint32_t w0 = ev.w[j - 16], w9 = ev.w[j - 7];
+                    const uint32_t lo = (w0 & 0xffff) + (s0 & 0xffff) + (w9 & 0xffff) + (s1 & 0xffff);
+                    const uint32_t c_lo = lo >> 16;
+                    const uint32_t hi = (w0 >> 16) + (s0 >> 16) + (w9 >> 16) + (s1 >> 16) + c_lo;
+                    const uint32_t c_hi = hi >> 16;
+                    put(RV32_SHA_EXTEND_cy_0, c_lo & 1); put(RV32_SHA_EXTEND_cy_1, c_lo >> 1);
+                    put(RV32_SHA_EXTEND_cy_2, c_hi & 1); put(RV32_SHA_EXTEND_cy_3, c_hi >> 1);
+                    sink.byte(B_RANGE - 1, ((nw & 0xff) << 8) | ((nw >> 8) & 0xff));
+                    sink.byte(B_RANGE - 1, (((nw >> 16) & 0xff) << 8) | (nw >> 24));
+                }
+                // the access: previous (shard, clk) of the word, gap to (shard, clk + 2)
+                const uint32_t psh = ev.prev_sh[j], pts = ev.prev_ts[j];
+                const uint32_t d = psh == S.index ? ev.clk + 2 - pts - 1 : S.index - psh - 1;
+                put(RV32_SHA_EXTEND_m_sh, psh); put(RV32_SHA_EXTEND_m_ts, pts); put(RV32_SHA_EXTEND_m_same, psh == S.index);
+                put(RV32_SHA_EXTEND_m_lo, d & 0xffff); put(RV32_SHA_EXTEND_m_hi, d >> 16);
+                sink.byte(B_U16 - 1, d & 0xffff);
+                sink.byte(B_RANGE - 1, (d >> 16) << 8);
+                if (j == 0) sink.byte(B_ADDR - 1, ((ev.ptr & 0xff) << 8) | (ev.ptr >> 24));
+            }
+        }
+    }
     const uint32_t lp = prep.log_n[RV32_CHIP_PROGRAM];
     T.log_n[RV32_CHIP_PROGRAM] = lp;
     T.main[RV32_CHIP_PROGRAM].assign((size_t)1 << lp, 0);
@@ -780,7 +864,7 @@ bool build_traces_host(const Program &prog, const ExecResult &res, size_t shard_
     if (res.unsupported) { if (err) *err = "unsupported " + res.unsupported_what; return false; }
     const ShardRec &S = res.shards[shard_pos];
     const bool last = shard_pos + 1 == res.shards.size();
-    if (!build_aux_host(ShardMeta{S.index, S.start_pc, S.next_pc, S.recs.size()}, S.alu, last ? &res.mem_rows : nullptr, res.exit_code, prep, out, err)) return false;
+    if (!build_aux_host(ShardMeta{S.index, S.start_pc, S.next_pc, S.recs.size()}, S.alu, S.sha_ext, last ? &res.mem_rows : nullptr, res.exit_code, prep, out, err)) return false;
     const size_t nc = (size_t)1 << T.log_n[RV32_CHIP_CPU];
     T.main[RV32_CHIP_CPU].assign((size_t)RV32_CPU_MAIN_W * nc, 0);
     std::vector<uint32_t> prog_idx_mult(prog.instrs.size(), 0);

@@ -196,7 +196,7 @@ class Run:
     def _run(self, max_cycles):
         pc, shard, i_in = self.entry, 1, 0
         size = 1 << self.log_shard
-        cur = dict(index=1, start_pc=pc, rows=[], alu=[])
+        cur = dict(index=1, start_pc=pc, rows=[], alu=[], sha_ext=[])
         while True:
             if self.cycles >= max_cycles:
                 raise Trap("cycle limit reached before HALT")
@@ -204,7 +204,7 @@ class Run:
                 cur["next_pc"] = pc
                 self.shards.append(cur)
                 shard, i_in = shard + 1, 0
-                cur = dict(index=shard, start_pc=pc, rows=[], alu=[])
+                cur = dict(index=shard, start_pc=pc, rows=[], alu=[], sha_ext=[])
             ins = self.text.get(pc)
             if ins is None:
                 raise Trap("pc outside text at pc 0x%x" % pc)
@@ -313,6 +313,32 @@ class Run:
                     row.maddr, row.m_prev, row.m_val = 11, a1, a1
                     if c < 8:
                         self.committed[c] = a1
+                elif b == 0x00300105:
+                    # SHA_EXTEND(a0 = w): w[16..63] of the SHA-256 message schedule in place; a1 (read through the port like
+                    # COMMIT's) must be 0; every word of the array is accessed once, at (shard, clk + 2)
+                    if a1 != 0:
+                        raise Trap("SHA_EXTEND with a1 != 0 at pc 0x%x" % pc)
+                    if c % 4 or c < 32 or c + 256 > ADDR_LIMIT:
+                        raise Trap("SHA_EXTEND pointer misaligned or out of range at pc 0x%x" % pc)
+                    row.mem = self._touch_reg(11, (shard, clk + 2))
+                    row.maddr, row.m_prev, row.m_val = 11, a1, a1
+                    rotr = lambda v, n: ((v >> n) | (v << (32 - n))) & M32
+                    w, old, prev = [], [], []
+                    for kk in range(64):
+                        wa = c + 4 * kk
+                        before = self._mem_word(wa)
+                        if kk < 16:
+                            w.append(before)
+                        else:
+                            x, y = w[kk - 15], w[kk - 2]
+                            s0 = rotr(x, 7) ^ rotr(x, 18) ^ (x >> 3)
+                            s1 = rotr(y, 17) ^ rotr(y, 19) ^ (y >> 10)
+                            w.append((s1 + w[kk - 7] + s0 + w[kk - 16]) & M32)
+                        old.append(before)
+                        prev.append(self.mem_t.get(wa, (0, 0)))
+                        self.mem[wa] = w[kk]
+                        self.mem_t[wa] = (shard, clk + 2)
+                    cur["sha_ext"].append(dict(clk=clk, ptr=c, w=w, old=old, prev=prev))
                 elif b == 0x1A:
                     pass
                 elif b == 0xF0:
@@ -537,9 +563,16 @@ def traces(run: Run, pos: int):
             is_commit = int(sid == 0x10)
             U[6] = is_commit
             U[7] = 0 if is_commit else inv(sid - 0x10)
-            put("commit_m", is_commit)
-            if is_commit:
-                U[0] = 11
+            # byte 1 of the code = 1: the call has a precompile chip; COMMIT and precompile rows read a1 through the memory
+            # port and send (t0 bytes, a0 bytes, a1 bytes, u_clk, u_sh) on the sys bus
+            is_pre = int(byts(b)[1] == 1)
+            U[1] = is_pre
+            U[2] = 0 if is_pre else inv(byts(b)[1] - 1)
+            put("sys_m", int(is_commit or is_pre))
+            if is_commit or is_pre:
+                U[3], U[21] = (clk, shard) if is_pre else (0, 0)
+                # the port's address expression u0 + 256 u1 + 65536 u2 + 2^24 u3 - (u21 + 2 u22 + 3 u23) is 11
+                U[0] = (11 - 256 * U[1] - 65536 * U[2] - (1 << 24) * U[3] + U[21]) % P
                 mem_port(row.m_prev, row.m_val, row.mem)
         putv("u", U)
         put("pb_hi", hi["pb"]); put("pc_hi", hi["pc"]); put("pa_hi", hi["pa"])
@@ -682,6 +715,43 @@ def traces(run: Run, pos: int):
                 lk.add(B_RANGE, byts(v)[0], byts(v)[1]); lk.add(B_RANGE, byts(v)[2], byts(v)[3])
             prev = addr
         out["mem_init"] = mat
+
+    # ---- sha_extend: 64 rows per call (rows 0..15 read w[j] into the window, rows 16..63 compute and write w[j])
+    if sh["sha_ext"]:
+        cid, chip = chips["sha_extend"]
+        mat = np.zeros((chip.main_width, 1 << log2ceil(64 * len(sh["sha_ext"]))), np.int64)
+        rotr = lambda v, n: ((v >> n) | (v << (32 - n))) & M32
+        for e, ev in enumerate(sh["sha_ext"]):
+            w = ev["w"]
+            for j in range(64):
+                put, putv = _col_setter(chip, mat, 64 * e + j)
+                put("is_real", 1); put("is_first", int(j == 0)); put("is_last", int(j == 63))
+                put("is_load", int(j < 16)); put("is_e", int(j == 15)); put("j", j)
+                put("j_inv", inv(j - 63) if j != 63 else 0)
+                put("clk", ev["clk"]); putv("p", byts(ev["ptr"]))
+                win = [w[j - 16 + k] if j - 16 + k >= 0 else 0 for k in range(16)]
+                for k in range(16):
+                    putv(f"w{k}", byts(win[k]))
+                x, y = win[1], win[14]
+                putv("xb", [(x >> t) & 1 for t in range(32)]); putv("yb", [(y >> t) & 1 for t in range(32)])
+                s0 = rotr(x, 7) ^ rotr(x, 18) ^ (x >> 3)
+                s1 = rotr(y, 17) ^ rotr(y, 19) ^ (y >> 10)
+                putv("s0", [s0 & 0xFFFF, s0 >> 16]); putv("s1", [s1 & 0xFFFF, s1 >> 16])
+                putv("nw", byts(w[j])); putv("old", byts(ev["old"][j]))
+                if j >= 16:
+                    lo = (win[0] & 0xFFFF) + (s0 & 0xFFFF) + (win[9] & 0xFFFF) + (s1 & 0xFFFF)
+                    hi_ = (win[0] >> 16) + (s0 >> 16) + (win[9] >> 16) + (s1 >> 16) + (lo >> 16)
+                    assert ((hi_ & 0xFFFF) << 16 | (lo & 0xFFFF)) == w[j]
+                    putv("cy", [(lo >> 16) & 1, lo >> 17, (hi_ >> 16) & 1, hi_ >> 17])
+                    lk.add(B_RANGE, byts(w[j])[0], byts(w[j])[1]); lk.add(B_RANGE, byts(w[j])[2], byts(w[j])[3])
+                psh, pts = ev["prev"][j]
+                d = ev["clk"] + 2 - pts - 1 if psh == sh["index"] else sh["index"] - psh - 1
+                put("m_sh", psh); put("m_ts", pts); put("m_same", int(psh == sh["index"]))
+                put("m_lo", d & 0xFFFF); put("m_hi", d >> 16)
+                lk.add(B_U16, d & 0xFFFF); lk.add(B_RANGE, d >> 16, 0)
+                if j == 0:
+                    lk.add(B_ADDR, byts(ev["ptr"])[0], byts(ev["ptr"])[3])
+        out["sha_extend"] = mat
 
     # ---- preprocessed chips and their multiplicity columns
     cidp, chipp = chips["program"]

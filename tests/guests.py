@@ -287,6 +287,50 @@ def arith(commit=True):
     return a.elf(), b"".join(struct.pack("<I", v) for v in exp)
 
 
+SYS_SHA_EXTEND = 0x00300105
+
+
+def sha_schedule_py(w16):
+    """w[0..63] of the SHA-256 message schedule (what the SHA_EXTEND precompile computes in place)"""
+    rotr = lambda v, n: ((v >> n) | (v << (32 - n))) & M32
+    w = list(w16)
+    for i in range(16, 64):
+        s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3)
+        s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10)
+        w.append((s1 + w[i - 7] + s0 + w[i - 16]) & M32)
+    return w
+
+
+def sha_extend(blocks=2, a1=0, ptr_off=0):
+    """SP1's SHA_EXTEND precompile (syscall 0x00_30_01_05, a0 = pointer to 64 words, a1 = 0) on `blocks` arrays: the second
+    array's first 16 words are the LAST 16 words the first call produced (memory written by one call is read by the next).
+    Returns (elf, expected result bytes): the 64 x blocks words go to fd 1, their checksum() to the public values.
+    a1 / ptr_off make the call invalid (it traps)."""
+    first = [(0x6A09E667 * (i + 1) + 0x1F83D9AB * (i * i)) & M32 for i in range(16)]
+    a = Asm()
+    buf = a.dword("w", first + [0] * (64 * blocks - 16 + 4))
+    exp = []
+    cur = first
+    for b in range(blocks):
+        base = buf + 256 * b
+        if b:
+            # copy the previous array's last 16 words to the start of this one
+            a.li("s1", base - 64)
+            a.li("s2", base)
+            for i in range(16):
+                a.lw("a5", "s1", 4 * i)
+                a.sw("a5", "s2", 4 * i)
+        a.li("a0", base + ptr_off)
+        a.li("a1", a1)
+        a.li("t0", SYS_SHA_EXTEND)
+        a.ecall()
+        w = sha_schedule_py(cur)
+        exp += w
+        cur = w[48:]
+    _finish(a, buf, 4 * len(exp))
+    return a.elf(), b"".join(struct.pack("<I", v) for v in exp)
+
+
 def commit_only(payload=b""):
     """The SP1 exit path alone: WRITE `payload` (a multiple of 4 bytes, from the data segment) to fd 3, hash it, COMMIT the
     eight digest words, HALT(0)."""

@@ -75,7 +75,8 @@ def _encshare_case():
     return guests.dkg_like("encshare"), guests.dkg_like_expected(buf, "encshare"), [buf]
 
 
-@pytest.mark.parametrize("log_shard,which", [(21, "bignum"), (8, "bignum"), (9, "shifts"), (10, "muldiv"), (16, "encshare")])
+@pytest.mark.parametrize("log_shard,which", [(21, "bignum"), (8, "bignum"), (9, "shifts"), (10, "muldiv"), (16, "encshare"),
+                                             (21, "sha_extend"), (9, "sha_extend")])
 def test_rv32_proof_bytes_equal_oracle(log_shard, which):
     from dvt_circuits_amd import capi
 

@@ -18,10 +18,11 @@ def air():
 
 
 def pv_extra(pv: bytes):
-    """the receiving side of the public-values bus (bus 5), which the verifier supplies: (k, the four bytes of word k of
-    SHA-256(public-value bytes)) for the eight digest words an SP1 guest COMMITs before HALT"""
+    """the receiving side of the COMMIT rows' tuples on the sys bus (bus 5), which the verifier supplies: (bytes of the
+    code 0x10, bytes of the index k, the four bytes of word k of SHA-256(public-value bytes), clk = 0, shard = 0) for the
+    eight digest words an SP1 guest COMMITs before HALT"""
     dg = hashlib.sha256(pv).digest()
-    return [(5, [k] + list(dg[4 * k:4 * k + 4]), -1, 1) for k in range(8)]
+    return [(5, [0x10, 0, 0, 0, k, 0, 0, 0] + list(dg[4 * k:4 * k + 4]) + [0, 0], -1, 1) for k in range(8)]
 
 
 def check_traces(air, elf, stdin=(), log_shard=0):
@@ -278,7 +279,7 @@ def test_commit_rows_bind_index_and_word(air):
     col = {n: i for i, n in names.items()}
     cpu = next(c for c in chips if air.chip(c["chip_id"]).name == b"cpu")
     main = cpu["main"]
-    rows = [r for r in range(main.shape[1]) if main[col["commit_m"], r] == 1]
+    rows = [r for r in range(main.shape[1]) if main[col["sys_m"], r] == 1]
     assert len(rows) == 8
     row, free = rows[3], set()
     for c in range(main.shape[0]):
@@ -378,7 +379,7 @@ def test_empty_public_values_commit_the_golden_digest_words():
     names = _cpu_names()
     col = {n: i for i, n in names.items()}
     cpu = next(c for c in chips if c["main"].shape[0] == len(names))["main"]
-    rows = [r for r in range(cpu.shape[1]) if cpu[col["commit_m"], r] == 1]
+    rows = [r for r in range(cpu.shape[1]) if cpu[col["sys_m"], r] == 1]
     assert len(rows) == 8
     for k, r in enumerate(rows):
         assert sum(int(cpu[col[f"c_{i}"], r]) << (8 * i) for i in range(4)) == k

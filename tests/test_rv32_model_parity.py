@@ -28,6 +28,8 @@ def cases():
         "bignum": (guests.bignum(2, limbs=3)[0], (), 9),
         "hint": (guests.hint_sum(), [struct.pack("<7I", *range(3, 10))], 21),
         "commit_only": (guests.commit_only(b"public-values"[:12]), (), 21),
+        "sha_extend": (guests.sha_extend()[0], (), 21),
+        "sha_extend_sharded": (guests.sha_extend(3)[0], (), 10),
         "encshare_n3": (guests.dkg_like("encshare"), [enc], 15),
     }
 
@@ -70,7 +72,7 @@ def test_model_traces_satisfy_the_air():
             assert bad == 0, (pos, ch["chip_id"], bc, br)
         groups.append((chips, pubs))
     dg = hashlib.sha256(run.public_values).digest()
-    extra = [(5, [k] + list(dg[4 * k:4 * k + 4]), -1, 1) for k in range(8)]
+    extra = [(5, [0x10, 0, 0, 0, k, 0, 0, 0] + list(dg[4 * k:4 * k + 4]) + [0, 0], -1, 1) for k in range(8)]
     assert air.logup_unbalanced(groups, extra=extra)[0] == 0
 
 

@@ -12,6 +12,7 @@ Chips
             final value/timestamp; image words are bound to mem_image
   shift     SLL/SRL/SRA rows, fed by the cpu chip over the alu bus (only in shards that shift)
   muldiv    MULH/MULHSU/DIV/DIVU/REM/REMU rows, same bus (only in shards that use them)
+  sha_extend  the SHA_EXTEND precompile (SHA-256 message schedule, 64 rows per call), fed over the sys bus
 
 Memory consistency is an offline-checking LogUp multiset over tuples
 (addr, byte0..3, timestamp): every access consumes the previous tuple of its
@@ -31,11 +32,12 @@ supplied, hence trusted and mutually exclusive) selector.
 """
 from .dsl import Chip, Expr, Machine, esum, word
 
-BUSES = {"program": 1, "byte": 2, "mem": 3, "image": 4, "pv": 5, "alu": 6}
+BUSES = {"program": 1, "byte": 2, "mem": 3, "image": 4, "sys": 5, "alu": 6}
 ALU_SLL, ALU_SRL, ALU_SRA = 1, 2, 3
 ALU_MULH, ALU_MULHSU, ALU_DIV, ALU_DIVU, ALU_REM, ALU_REMU = 4, 5, 6, 7, 8, 9
 SYS_COMMIT = 0x10
 SYS_HINT_LEN = 0xF0
+SYS_SHA_EXTEND = 0x00300105     # SP1's syscall code: byte 0 = id, byte 1 = 1 "has a precompile table", byte 2 = extra cycles
 REG_A1 = 11
 
 # byte-table opcodes
@@ -131,7 +133,7 @@ def build_cpu():
     pa_prev = ch.cols("pa_prev", 4)
     pa_ts, pa_lo, pa_hi = ch.col("pa_ts"), ch.col("pa_lo"), ch.col("pa_hi")
     U = ch.cols("u", UNION_W)
-    commit_m = ch.col("commit_m")
+    sys_m = ch.col("sys_m")
 
     # ---------------- row bookkeeping
     ch.assert_bool(is_real)
@@ -302,8 +304,8 @@ def build_cpu():
     ch.assert_zero((F["is_lw"] + F["is_sw"]) * (o1 + o2 + o3))                      # word access: aligned
     ch.assert_zero((F["is_lh"] + F["is_lhu"] + F["is_sh"]) * (o1 + o3))              # halfword access: even
     maddr = word(s) - o_val
-    # (COMMIT ecalls read their second argument, register a1, through this port: commit_m rows pin the address to 11)
-    sel_port = sel_mem + commit_m
+    # (COMMIT and precompile ecalls read their second argument, register a1, through this port: sys_m rows pin the address to 11)
+    sel_port = sel_mem + sys_m
     ch.receive("mem", [maddr] + mp + [m_sh, m_ts], sel_port)
     ch.send("mem", [maddr] + mv + [shard, clk + 2], sel_port)
     ch.assert_zero(sel_port * (m_same * (m_same - 1)))
@@ -363,21 +365,33 @@ def build_cpu():
         ch.assert_zero(ec * ((1 - is_hl) * (a[i] - b[i])))
     # COMMIT (id 0x10, a0 = index, a1 = word) — SP1's syscall contract: the guest hashes the bytes
     # it wrote to fd 3 with SHA-256 and commits the eight digest words, COMMIT(k, digest word k), before HALT
-    # (reference crates/finalization_prove/src/main.rs:26-32 via sp1_zkvm::io::commit).  The row reads a1 = x11 through
-    # the memory port (address bytes u[0..3] = 11, no byte offset, value unchanged) and sends (index, bytes of the word)
-    # on the "pv" bus; the VERIFIER supplies the receiving side from SHA-256 of the claimed public-value bytes, so they
-    # are bound to the proof.
+    # (reference crates/finalization_prove/src/main.rs:26-32 via sp1_zkvm::io::commit).
+    # PRECOMPILES: SP1 syscall codes carry "this call has a table" in byte 1; such rows (is_pre) hand (code, a0, a1, clk,
+    # shard) to the precompile's own chip, which does the memory accesses of the call at (shard, clk + 2).
+    # Both kinds of row ("sys rows", multiplicity sys_m) read a1 = x11 through the memory port (address pinned to 11 by ONE
+    # affine constraint on the address expression, value unchanged) and send
+    #     [t0 bytes, a0 bytes, a1 bytes, u_clk, u_sh]        on the "sys" bus,
+    # u_clk = u_sh = 0 on COMMIT rows (the VERIFIER supplies the receiving side from SHA-256 of the claimed public-value
+    # bytes, so they are bound to the proof), u_clk = clk and u_sh = shard on precompile rows.
+    # Witness cells (free on sys rows because only the address EXPRESSION is pinned): u[1] is_pre, u[2] 1 / (t0 byte 1 - 1),
+    # u[3] u_clk, u[21] u_sh; u[0] balances the address expression.
     is_commit, cm_inv = U[6], U[7]
     ch.assert_zero(ec * (is_commit * (is_commit - 1)))
     ch.assert_zero(ec * (is_commit * (word(b) - SYS_COMMIT)))
     ch.assert_zero(ec * ((word(b) - SYS_COMMIT) * cm_inv - (1 - is_commit)))
-    ch.assert_zero(commit_m - ec * is_commit)
-    ch.assert_zero(commit_m * (s[0] - REG_A1))
-    for x in (s[1], s[2], s[3], o1, o2, o3):
-        ch.assert_zero(commit_m * x)
+    is_pre, pre_inv, u_clk, u_sh = U[1], U[2], U[3], U[21]
+    ch.assert_zero(ec * (is_pre * (is_pre - 1)))
+    ch.assert_zero(ec * (is_pre * (b[1] - 1)))
+    ch.assert_zero(ec * ((b[1] - 1) * pre_inv - (1 - is_pre)))
+    ch.assert_zero(sys_m - ec * (is_commit + is_pre))
+    ch.assert_zero(sys_m * (maddr - REG_A1))
     for i in range(4):
-        ch.assert_zero(commit_m * (mv[i] - mp[i]))
-    ch.send("pv", [word(c)] + mv, commit_m)
+        ch.assert_zero(sys_m * (mv[i] - mp[i]))
+    ch.assert_zero(ec * (is_pre * (u_clk - clk)))
+    ch.assert_zero(ec * (is_pre * (u_sh - shard)))
+    ch.assert_zero(ec * (is_commit * u_clk))
+    ch.assert_zero(ec * (is_commit * u_sh))
+    ch.send("sys", b + c + mv + [u_clk, u_sh], sys_m)
     ch.quotient_parts = 4
     ch.logup_parts = 5
     return ch
@@ -551,6 +565,106 @@ def build_muldiv():
     return ch
 
 
+def build_sha_extend():
+    """SHA_EXTEND precompile (SP1 syscall 0x00_30_01_05, a0 = pointer to a 64-word array, a1 = 0): w[16..63] of the SHA-256
+    message schedule, w[i] = s1(w[i-2]) + w[i-7] + s0(w[i-15]) + w[i-16], computed in place.
+    64 rows per call: rows j = 0..15 READ w[j] into a 16-word window carried from row to row, rows j = 16..63 compute the
+    next word from the window and WRITE it; every row makes exactly one memory access, at (shard, clk + 2) of the ECALL
+    (64 distinct addresses, so one timestamp serves the whole call and the cpu clock does not skip).
+    The first row of a call receives the cpu chip's tuple from the sys bus."""
+    ch = Chip("sha_extend")
+    shard = ch.pub(PUB_SHARD)
+    is_real, is_first, is_last, is_load, is_e = ch.col("is_real"), ch.col("is_first"), ch.col("is_last"), ch.col("is_load"), ch.col("is_e")
+    j, j_inv, clk = ch.col("j"), ch.col("j_inv"), ch.col("clk")
+    p = ch.cols("p", 4)                                   # w_ptr
+    W = [ch.cols(f"w{k}", 4) for k in range(16)]            # window: row j holds w[j-16+k] in W[k] (garbage before it fills)
+    nw, old = ch.cols("nw", 4), ch.cols("old", 4)          # the word this row reads / writes, the memory word it replaces
+    xb, yb = ch.cols("xb", 32), ch.cols("yb", 32)          # bits of W[1] (s0 input) and of W[14] (s1 input)
+    s0, s1 = ch.cols("s0", 2), ch.cols("s1", 2)            # 16-bit halves of s0(W[1]), s1(W[14])
+    cy = ch.cols("cy", 4)                                  # two carry bits per half
+    m_sh, m_ts, m_same, m_lo, m_hi = ch.col("m_sh"), ch.col("m_ts"), ch.col("m_same"), ch.col("m_lo"), ch.col("m_hi")
+    nr = is_real.next()
+    # ---- row structure
+    for f in (is_real, is_first, is_last, is_load, is_e):
+        ch.assert_bool(f)
+    ch.assert_zero(nr * (1 - is_real), "trans")                       # real rows first
+    ch.assert_eq(is_first, is_real, "first")
+    ch.assert_zero(nr * (is_first.next() - is_last), "trans")         # a call starts right after the previous one ends
+    ch.assert_zero((is_real - nr) * (1 - is_last), "trans")           # ... and the table ends with a complete call
+    ch.assert_zero(is_real * (1 - is_last), "last")
+    for f in (is_first, is_last, is_load, is_e):
+        ch.assert_zero((1 - is_real) * f)
+    ch.assert_zero(is_first * j)
+    ch.assert_zero(is_last * (j - 63))
+    ch.assert_zero(is_real * ((j - 63) * j_inv - (1 - is_last)))
+    inner = is_real - is_last           # 1 iff this row and the next belong to the same call (is_last implies is_real)
+    ch.assert_zero(inner * (j.next() - j - 1), "trans")
+    ch.assert_zero(inner * (clk.next() - clk), "trans")
+    for i in range(4):
+        ch.assert_zero(inner * (p[i].next() - p[i]), "trans")
+    # is_load = 1 on rows 0..15: starts at 1, ends at 0, drops exactly where is_e marks row 15
+    ch.assert_zero(is_first * (1 - is_load))
+    ch.assert_zero(is_last * is_load)
+    ch.assert_zero(is_e * (j - 15))
+    ch.assert_zero(inner * (is_load - is_load.next() - is_e), "trans")
+    # ---- the call: (code bytes, a0 bytes, a1 = 0, clk, shard) from the cpu chip; pointer word-aligned and below 0x38000000
+    code = [(SYS_SHA_EXTEND >> (8 * i)) & 0xFF for i in range(4)]
+    ch.receive("sys", code + p + [0, 0, 0, 0] + [clk, shard], is_first)
+    ch.send("byte", [B_ADDR, 0, p[0], p[3]], is_first)
+    # ---- window
+    for k in range(15):
+        for i in range(4):
+            ch.assert_zero(inner * (W[k][i].next() - W[k + 1][i]), "trans")
+    for i in range(4):
+        ch.assert_zero(inner * (W[15][i].next() - nw[i]), "trans")
+    # ---- s0(x) = rotr7 ^ rotr18 ^ shr3 of x = W[1], s1(y) = rotr17 ^ rotr19 ^ shr10 of y = W[14], from bits
+    for bits, wd in ((xb, W[1]), (yb, W[14])):
+        for t in bits:
+            ch.assert_bool(t)
+        for i in range(4):
+            ch.assert_eq(wd[i], esum((1 << k) * bits[8 * i + k] for k in range(8)))
+
+    def xor3(a, b_, c_):
+        return a + b_ + c_ - 2 * (a * b_ + a * c_ + b_ * c_) + 4 * (a * b_ * c_)
+
+    def xor2(a, b_):
+        return a + b_ - 2 * (a * b_)
+
+    def sigma(bits, r1, r2, sh):
+        out = []
+        for k in range(32):
+            a_, b_ = bits[(k + r1) % 32], bits[(k + r2) % 32]
+            out.append(xor3(a_, b_, bits[k + sh]) if k + sh < 32 else xor2(a_, b_))
+        return out
+
+    g0, g1 = sigma(xb, 7, 18, 3), sigma(yb, 17, 19, 10)
+    for h in range(2):
+        ch.assert_eq(s0[h], esum((1 << k) * g0[16 * h + k] for k in range(16)))
+        ch.assert_eq(s1[h], esum((1 << k) * g1[16 * h + k] for k in range(16)))
+    # ---- compute rows: nw = s1 + w[j-7] + s0 + w[j-16] mod 2^32, in 16-bit halves (carries 0..3 as two bits each)
+    for t in cy:
+        ch.assert_bool(t)
+    half = lambda wd, h: wd[2 * h] + 256 * wd[2 * h + 1]
+    c_lo, c_hi = cy[0] + 2 * cy[1], cy[2] + 2 * cy[3]
+    ch.assert_zero((1 - is_load) * (half(W[0], 0) + s0[0] + half(W[9], 0) + s1[0] - half(nw, 0) - 65536 * c_lo))
+    ch.assert_zero((1 - is_load) * (half(W[0], 1) + s0[1] + half(W[9], 1) + s1[1] + c_lo - half(nw, 1) - 65536 * c_hi))
+    ch.send("byte", [B_RANGE, 0, nw[0], nw[1]], is_real - is_load)
+    ch.send("byte", [B_RANGE, 0, nw[2], nw[3]], is_real - is_load)
+    # ---- the row's memory access: word j of the array, read (unchanged) on load rows, written on compute rows
+    addr = word(p) + 4 * j
+    for i in range(4):
+        ch.assert_zero(is_load * (old[i] - nw[i]))
+    ch.receive("mem", [addr] + old + [m_sh, m_ts], is_real)
+    ch.send("mem", [addr] + nw + [shard, clk + 2], is_real)
+    ch.assert_zero(is_real * (m_same * (m_same - 1)))
+    ch.assert_zero(is_real * (m_same * (shard - m_sh)))
+    ch.assert_zero(is_real * (m_same * (clk + 2 - m_ts - 1) + (1 - m_same) * (shard - m_sh - 1) - m_lo - 65536 * m_hi))
+    ch.send("byte", [B_U16, 0, m_lo, 0], is_real)
+    ch.send("byte", [B_RANGE, 0, m_hi, 0], is_real)
+    ch.quotient_parts = 2
+    return ch
+
+
 def build_mem_image():
     ch = Chip("mem_image")
     addr, v, real = ch.prep("addr"), ch.preps("v", 4), ch.prep("is_real")
@@ -593,4 +707,5 @@ def build_mem_init():
 
 
 def build():
-    return Machine("rv32", [build_program(), build_byte(), build_cpu(), build_mem_image(), build_mem_init(), build_shift(), build_muldiv()], BUSES)
+    return Machine("rv32", [build_program(), build_byte(), build_cpu(), build_mem_image(), build_mem_init(), build_shift(), build_muldiv(),
+                            build_sha_extend()], BUSES)
