@@ -41,11 +41,12 @@ constexpr int N_BYTE_OPS = 8;  // multiplicity columns of the byte chip, in this
 constexpr uint32_t ADDR_LIMIT = 0x38000000u;  // tools/airgen/rv32.py ADDR_TOP_BYTE: address + address gap stays below p
 constexpr uint32_t SYS_COMMIT = 0x10;
 constexpr uint32_t SYS_SHA_EXTEND = 0x00300105u;  // SP1 syscall code (byte 1 = 1: the call has a precompile table)
+constexpr uint32_t SYS_SHA_COMPRESS = 0x00010106u;
 constexpr uint32_t REG_A1 = 11;
 constexpr uint32_t MAX_SHARDS = 65535;        // shard numbers travel as 16-bit halves of the cycle records
 constexpr uint32_t ALU_SLL = 1, ALU_SRL = 2, ALU_SRA = 3;  // alu-bus opcodes (chips outside the cpu chip): shift chip
 constexpr uint32_t ALU_MULH = 4, ALU_MULHSU = 5, ALU_DIV = 6, ALU_DIVU = 7, ALU_REM = 8, ALU_REMU = 9;  // muldiv chip
-constexpr int N_CHIPS = 8;  // program, byte, cpu, mem_image, mem_init, shift, muldiv, sha_extend
+constexpr int N_CHIPS = 9;  // program, byte, cpu, mem_image, mem_init, shift, muldiv, sha_extend, sha_compress
 constexpr uint32_t N_PUBLIC = 5;  // start_pc, next_pc, exit_code, shard, is_last
 
 // dense dispatch code of the interpreter (one case per instruction form: which ports it drives is static per case)
@@ -132,9 +133,16 @@ struct ShaExtEvent {
 };
 
 // One shard = up to 2^log_shard consecutive cycles; shards are numbered from 1.
+// one SHA_COMPRESS call: the 64 schedule words and the 8 state words as read, with the (shard, clk) each carried before
+struct ShaCmpEvent {
+    uint32_t clk, w_ptr, h_ptr;
+    uint32_t w[64], hs[8], w_ts[64], h_ts[8];
+    uint16_t w_sh[64], h_sh[8];
+};
 struct ShardRec {
     std::vector<AluEvent> alu;   // instructions of this shard proven by chips outside the cpu chip
     std::vector<ShaExtEvent> sha_ext;   // precompile calls of this shard
+    std::vector<ShaCmpEvent> sha_cmp;
     uint32_t index = 0, start_pc = 0, next_pc = 0;
     std::vector<CycleRec> recs;
 };
@@ -189,6 +197,7 @@ struct ShardOut {
     size_t n_recs = 0;
     std::vector<AluEvent> alu;
     std::vector<ShaExtEvent> sha_ext;
+    std::vector<ShaCmpEvent> sha_cmp;
     uint32_t index = 0, start_pc = 0, next_pc = 0;
 };
 
@@ -462,7 +471,7 @@ struct ShardMeta {
     size_t n_recs;
 };
 bool build_aux_host(const ShardMeta &meta, const std::vector<AluEvent> &alu, const std::vector<ShaExtEvent> &sha_ext,
-                    const std::vector<MemInitRow> *mem_rows, int exit_code, const HostPrep &prep, HostTraces *out, std::string *err);
+                    const std::vector<ShaCmpEvent> &sha_cmp, const std::vector<MemInitRow> *mem_rows, int exit_code, const HostPrep &prep, HostTraces *out, std::string *err);
 // the whole shard on the host, cpu chip included (debug C-ABI, tests)
 bool build_traces_host(const Program &prog, const ExecResult &res, size_t shard_pos, const HostPrep &prep, HostTraces *out, std::string *err);
 // instruction index -> row of the program table (provable instructions only; others map to row 0 and never occur)

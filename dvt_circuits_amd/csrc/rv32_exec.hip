@@ -8,6 +8,14 @@
 
 namespace dvt {
 namespace rv32 {
+static const uint32_t SHA256_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
 
 // ------------------------------------------------------------------ decode
 static inline uint32_t bits(uint32_t x, int hi, int lo) { return (x >> lo) & ((1u << (hi - lo + 1)) - 1); }
@@ -244,6 +252,7 @@ void Vm::run_shard(bool trace, ShardOut *out, uint64_t max_total_cycles) {
         out->n_recs = 0;
         out->alu.clear();
         out->sha_ext.clear();
+        out->sha_cmp.clear();
         run<true>(out, budget);
         out->next_pc = pc;   // 0 after HALT
     } else {
@@ -422,6 +431,56 @@ L_ECALL: {
         }
         break;
     }
+    case SYS_SHA_COMPRESS: {  // SHA_COMPRESS(a0 = w, a1 = state): the SHA-256 compression function, state updated in place
+        if (c % 4 || c < 32 || (uint64_t)c + 256 > ADDR_LIMIT || a1 % 4 || a1 < 32 || (uint64_t)a1 + 32 > ADDR_LIMIT) {
+            why = "SHA_COMPRESS pointer misaligned or out of range"; goto trapped;
+        }
+        if (a1 + 32 > c && c + 256 > a1) { why = "SHA_COMPRESS arrays overlap"; goto trapped; }
+        {
+            Cell &r11 = regs[REG_A1];
+            if (TRACE) { rec.m_prev = r11.val; rec.m_ts = r11.ts(); shm = r11.sh(); }
+            r11.tsh = sh64 | (clk + 2);
+        }
+        ShaCmpEvent *ev = nullptr;
+        if (TRACE) { out->sha_cmp.emplace_back(); ev = &out->sha_cmp.back(); ev->clk = clk; ev->w_ptr = c; ev->h_ptr = a1; }
+        uint32_t w[64], hs[8];
+        auto touch = [&](uint32_t ad) -> Cell & {
+            Cell &cell = at(ad);
+            if (!(cell.flags & (FL_TOUCHED | FL_IMG))) { cell.flags |= FL_TOUCHED; if (collect_output) first_touch.emplace_back(ad, cell.val); }
+            return cell;
+        };
+        for (uint32_t k = 0; k < 8; k++) {    // the state is read at clk + 2 ...
+            Cell &cell = touch(a1 + 4 * k);
+            hs[k] = cell.val;
+            if (TRACE) { ev->hs[k] = cell.val; ev->h_ts[k] = cell.ts(); ev->h_sh[k] = (uint16_t)cell.sh(); }
+            cell.tsh = sh64 | (clk + 2);
+        }
+        for (uint32_t k = 0; k < 64; k++) {
+            Cell &cell = touch(c + 4 * k);
+            w[k] = cell.val;
+            if (TRACE) { ev->w[k] = cell.val; ev->w_ts[k] = cell.ts(); ev->w_sh[k] = (uint16_t)cell.sh(); }
+            cell.tsh = sh64 | (clk + 2);
+        }
+        uint32_t v[8];
+        for (int k = 0; k < 8; k++) v[k] = hs[k];
+        for (uint32_t i = 0; i < 64; i++) {
+            const uint32_t e_ = v[4], a_ = v[0];
+            const uint32_t S1 = ((e_ >> 6) | (e_ << 26)) ^ ((e_ >> 11) | (e_ << 21)) ^ ((e_ >> 25) | (e_ << 7));
+            const uint32_t chv = (e_ & v[5]) ^ (~e_ & v[6]);
+            const uint32_t t1 = v[7] + S1 + chv + SHA256_K[i] + w[i];
+            const uint32_t S0 = ((a_ >> 2) | (a_ << 30)) ^ ((a_ >> 13) | (a_ << 19)) ^ ((a_ >> 22) | (a_ << 10));
+            const uint32_t mj = (a_ & v[1]) ^ (a_ & v[2]) ^ (v[1] & v[2]);
+            for (int k = 7; k > 0; k--) v[k] = v[k - 1];
+            v[4] += t1;
+            v[0] = t1 + S0 + mj;
+        }
+        for (uint32_t k = 0; k < 8; k++) {    // ... and written back at clk + 3
+            Cell &cell = at(a1 + 4 * k);
+            cell.val = hs[k] + v[k];
+            cell.tsh = sh64 | (clk + 3);
+        }
+        break;
+    }
     case 0x1a: break;  // COMMIT_DEFERRED_PROOFS: no-op (no recursion in core proofs)
     case 0xf0: a = next_input < stdin_bufs->size() ? (uint32_t)(*stdin_bufs)[next_input].size() : 0; break;
     case 0xf1: {  // HINT_READ(ptr = a0, len = a1): the words become initial memory (must be untouched so far)
@@ -524,6 +583,7 @@ void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin
             S.recs.assign(out.recs, out.recs + out.n_recs);
             S.alu = out.alu;
             S.sha_ext = out.sha_ext;
+            S.sha_cmp = out.sha_cmp;
         }
         if (vm.halted || !vm.error.empty()) break;
         if (!vm.next_shard()) break;
@@ -615,7 +675,7 @@ std::vector<uint32_t> program_row_map(const Program &prog) {
 }
 
 bool build_aux_host(const ShardMeta &S, const std::vector<AluEvent> &alu, const std::vector<ShaExtEvent> &sha_ext,
-                    const std::vector<MemInitRow> *mem_rows, int exit_code, const HostPrep &prep, HostTraces *out, std::string *err) {
+                    const std::vector<ShaCmpEvent> &sha_cmp, const std::vector<MemInitRow> *mem_rows, int exit_code, const HostPrep &prep, HostTraces *out, std::string *err) {
     HostTraces &T = *out;
     if (S.n_recs == 0) { if (err) *err = "no cycles to prove"; return false; }
     const bool last = mem_rows != nullptr;
@@ -847,6 +907,83 @@ bool build_aux_host(const ShardMeta &S, const std::vector<AluEvent> &alu, const 
             }
         }
     }
+    // sha_compress chip: 80 rows per SHA_COMPRESS call
+    T.present[RV32_CHIP_SHA_COMPRESS] = !sha_cmp.empty();
+    T.log_n[RV32_CHIP_SHA_COMPRESS] = 0;
+    if (!sha_cmp.empty()) {
+        const uint32_t lx = ceil_log2(sha_cmp.size() * 80);
+        const size_t nx = (size_t)1 << lx;
+        T.log_n[RV32_CHIP_SHA_COMPRESS] = lx;
+        auto &H = T.main[RV32_CHIP_SHA_COMPRESS];
+        H.assign((size_t)RV32_SHA_COMPRESS_MAIN_W * nx, 0);
+        auto rotr = [](uint32_t x, int n) { return (x >> n) | (x << (32 - n)); };
+        for (size_t e = 0; e < sha_cmp.size(); e++) {
+            const ShaCmpEvent &ev = sha_cmp[e];
+            uint32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // working variables a..h at the START of the row
+            for (uint32_t j = 0; j < 80; j++) {
+                const size_t row = e * 80 + j;
+                const uint32_t g = j >> 3, o = j & 7;
+                auto put = [&](int col, uint32_t x) { H[(size_t)col * nx + row] = x; };
+                auto put_word = [&](int col0, uint32_t x) { for (int i = 0; i < 4; i++) put(col0 + i, (x >> (8 * i)) & 0xff); };
+                auto put_bits = [&](int col0, uint32_t x) { for (int k = 0; k < 32; k++) put(col0 + k, (x >> k) & 1); };
+                put(RV32_SHA_COMPRESS_is_real, 1); put(RV32_SHA_COMPRESS_is_first, j == 0); put(RV32_SHA_COMPRESS_is_last, j == 79);
+                put(RV32_SHA_COMPRESS_oc_0 + o, 1); put(RV32_SHA_COMPRESS_gr_0 + g, 1);
+                put(RV32_SHA_COMPRESS_clk, ev.clk);
+                put_word(RV32_SHA_COMPRESS_wp_0, ev.w_ptr); put_word(RV32_SHA_COMPRESS_hp_0, ev.h_ptr);
+                put_bits(RV32_SHA_COMPRESS_ab_0, v[0]); put_bits(RV32_SHA_COMPRESS_bb_0, v[1]); put_bits(RV32_SHA_COMPRESS_cb_0, v[2]);
+                put_bits(RV32_SHA_COMPRESS_eb_0, v[4]); put_bits(RV32_SHA_COMPRESS_fb_0, v[5]); put_bits(RV32_SHA_COMPRESS_gb_0, v[6]);
+                put(RV32_SHA_COMPRESS_d_0, v[3] & 0xffff); put(RV32_SHA_COMPRESS_d_1, v[3] >> 16);
+                put(RV32_SHA_COMPRESS_h_0, v[7] & 0xffff); put(RV32_SHA_COMPRESS_h_1, v[7] >> 16);
+                const uint32_t S1 = rotr(v[4], 6) ^ rotr(v[4], 11) ^ rotr(v[4], 25), S0 = rotr(v[0], 2) ^ rotr(v[0], 13) ^ rotr(v[0], 22);
+                const uint32_t mj = (v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2]), chv = (v[4] & v[5]) ^ (~v[4] & v[6]);
+                put(RV32_SHA_COMPRESS_s1_0, S1 & 0xffff); put(RV32_SHA_COMPRESS_s1_1, S1 >> 16);
+                put(RV32_SHA_COMPRESS_s0_0, S0 & 0xffff); put(RV32_SHA_COMPRESS_s0_1, S0 >> 16);
+                put(RV32_SHA_COMPRESS_mj_0, mj & 0xffff); put(RV32_SHA_COMPRESS_mj_1, mj >> 16);
+                // the access of this row
+                uint32_t addr, before, after, psh, pts, ts = ev.clk + 2;
+                if (g == 0) { addr = ev.h_ptr + 4 * (7 - o); before = after = ev.hs[7 - o]; psh = ev.h_sh[7 - o]; pts = ev.h_ts[7 - o]; }
+                else if (g <= 8) { const uint32_t i = 8 * (g - 1) + o; addr = ev.w_ptr + 4 * i; before = after = ev.w[i]; psh = ev.w_sh[i]; pts = ev.w_ts[i]; }
+                else { addr = ev.h_ptr + 4 * (7 - o); before = ev.hs[7 - o]; after = before + v[7]; psh = (uint16_t)S.index; pts = ev.clk + 2; ts = ev.clk + 3; }
+                put(RV32_SHA_COMPRESS_maddr, addr);
+                put_word(RV32_SHA_COMPRESS_mv_0, after); put_word(RV32_SHA_COMPRESS_mo_0, before);
+                const uint32_t dgap = psh == S.index ? ts - pts - 1 : S.index - psh - 1;
+                put(RV32_SHA_COMPRESS_m_sh, psh); put(RV32_SHA_COMPRESS_m_ts, pts); put(RV32_SHA_COMPRESS_m_same, psh == S.index);
+                put(RV32_SHA_COMPRESS_m_lo, dgap & 0xffff); put(RV32_SHA_COMPRESS_m_hi, dgap >> 16);
+                sink.byte(B_U16 - 1, dgap & 0xffff);
+                sink.byte(B_RANGE - 1, (dgap >> 16) << 8);
+                if (j == 0) {
+                    sink.byte(B_ADDR - 1, ((ev.w_ptr & 0xff) << 8) | (ev.w_ptr >> 24));
+                    sink.byte(B_ADDR - 1, ((ev.h_ptr & 0xff) << 8) | (ev.h_ptr >> 24));
+                }
+                // next row's variables
+                uint32_t nv[8];
+                for (int k = 7; k > 0; k--) nv[k] = v[k - 1];
+                nv[0] = 0;
+                if (g == 0) nv[0] = before;
+                else if (g <= 8) {
+                    const uint32_t i = 8 * (g - 1) + o, K = SHA256_K[i], wv = ev.w[i];
+                    // e' = d + T1, a' = T1 + T2 in 16-bit halves: the carries are witnesses
+                    const uint32_t lo_t = (v[7] & 0xffff) + (S1 & 0xffff) + (chv & 0xffff) + (K & 0xffff) + (wv & 0xffff);
+                    const uint32_t hi_t = (v[7] >> 16) + (S1 >> 16) + (chv >> 16) + (K >> 16) + (wv >> 16);
+                    const uint32_t e_lo = lo_t + (v[3] & 0xffff), ce_lo = e_lo >> 16, e_hi = hi_t + (v[3] >> 16) + ce_lo, ce_hi = e_hi >> 16;
+                    const uint32_t a_lo = lo_t + (S0 & 0xffff) + (mj & 0xffff), ca_lo = a_lo >> 16;
+                    const uint32_t a_hi = hi_t + (S0 >> 16) + (mj >> 16) + ca_lo, ca_hi = a_hi >> 16;
+                    for (int k = 0; k < 3; k++) {
+                        put(RV32_SHA_COMPRESS_ce_0 + k, (ce_lo >> k) & 1); put(RV32_SHA_COMPRESS_ce_0 + 3 + k, (ce_hi >> k) & 1);
+                        put(RV32_SHA_COMPRESS_ca_0 + k, (ca_lo >> k) & 1); put(RV32_SHA_COMPRESS_ca_0 + 3 + k, (ca_hi >> k) & 1);
+                    }
+                    nv[4] = (e_lo & 0xffff) | (e_hi << 16);
+                    nv[0] = (a_lo & 0xffff) | (a_hi << 16);
+                } else {
+                    const uint32_t lo = (before & 0xffff) + (v[7] & 0xffff), hi2 = (before >> 16) + (v[7] >> 16) + (lo >> 16);
+                    put(RV32_SHA_COMPRESS_cf_0, lo >> 16); put(RV32_SHA_COMPRESS_cf_1, hi2 >> 16);
+                    sink.byte(B_RANGE - 1, ((after & 0xff) << 8) | ((after >> 8) & 0xff));
+                    sink.byte(B_RANGE - 1, (((after >> 16) & 0xff) << 8) | (after >> 24));
+                }
+                for (int k = 0; k < 8; k++) v[k] = nv[k];
+            }
+        }
+    }
     const uint32_t lp = prep.log_n[RV32_CHIP_PROGRAM];
     T.log_n[RV32_CHIP_PROGRAM] = lp;
     T.main[RV32_CHIP_PROGRAM].assign((size_t)1 << lp, 0);
@@ -864,7 +1001,7 @@ bool build_traces_host(const Program &prog, const ExecResult &res, size_t shard_
     if (res.unsupported) { if (err) *err = "unsupported " + res.unsupported_what; return false; }
     const ShardRec &S = res.shards[shard_pos];
     const bool last = shard_pos + 1 == res.shards.size();
-    if (!build_aux_host(ShardMeta{S.index, S.start_pc, S.next_pc, S.recs.size()}, S.alu, S.sha_ext, last ? &res.mem_rows : nullptr, res.exit_code, prep, out, err)) return false;
+    if (!build_aux_host(ShardMeta{S.index, S.start_pc, S.next_pc, S.recs.size()}, S.alu, S.sha_ext, S.sha_cmp, last ? &res.mem_rows : nullptr, res.exit_code, prep, out, err)) return false;
     const size_t nc = (size_t)1 << T.log_n[RV32_CHIP_CPU];
     T.main[RV32_CHIP_CPU].assign((size_t)RV32_CPU_MAIN_W * nc, 0);
     std::vector<uint32_t> prog_idx_mult(prog.instrs.size(), 0);

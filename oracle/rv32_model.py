@@ -20,6 +20,13 @@ P = 2013265921
 M32 = 0xFFFFFFFF
 ADDR_LIMIT = 0x38000000
 B_AND, B_OR, B_XOR, B_LTU, B_MSB, B_RANGE, B_U16, B_ADDR = 1, 2, 3, 4, 5, 6, 7, 8
+SHA_K = [
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2]
 ALU_CODES = dict(sll=1, srl=2, sra=3, mulh=4, mulhsu=5, div=6, divu=7, rem=8, remu=9)
 
 
@@ -196,7 +203,7 @@ class Run:
     def _run(self, max_cycles):
         pc, shard, i_in = self.entry, 1, 0
         size = 1 << self.log_shard
-        cur = dict(index=1, start_pc=pc, rows=[], alu=[], sha_ext=[])
+        cur = dict(index=1, start_pc=pc, rows=[], alu=[], sha_ext=[], sha_cmp=[])
         while True:
             if self.cycles >= max_cycles:
                 raise Trap("cycle limit reached before HALT")
@@ -204,7 +211,7 @@ class Run:
                 cur["next_pc"] = pc
                 self.shards.append(cur)
                 shard, i_in = shard + 1, 0
-                cur = dict(index=shard, start_pc=pc, rows=[], alu=[], sha_ext=[])
+                cur = dict(index=shard, start_pc=pc, rows=[], alu=[], sha_ext=[], sha_cmp=[])
             ins = self.text.get(pc)
             if ins is None:
                 raise Trap("pc outside text at pc 0x%x" % pc)
@@ -339,6 +346,37 @@ class Run:
                         self.mem[wa] = w[kk]
                         self.mem_t[wa] = (shard, clk + 2)
                     cur["sha_ext"].append(dict(clk=clk, ptr=c, w=w, old=old, prev=prev))
+                elif b == 0x00010106:
+                    # SHA_COMPRESS(a0 = w, a1 = state): 64 rounds of the SHA-256 compression function over the schedule
+                    # words, state += result in place; all reads at (shard, clk + 2), the eight write-backs at clk + 3
+                    if c % 4 or c < 32 or c + 256 > ADDR_LIMIT or a1 % 4 or a1 < 32 or a1 + 32 > ADDR_LIMIT:
+                        raise Trap("SHA_COMPRESS pointer misaligned or out of range at pc 0x%x" % pc)
+                    if a1 + 32 > c and c + 256 > a1:
+                        raise Trap("SHA_COMPRESS arrays overlap at pc 0x%x" % pc)
+                    row.mem = self._touch_reg(11, (shard, clk + 2))
+                    row.maddr, row.m_prev, row.m_val = 11, a1, a1
+                    rotr = lambda v, n: ((v >> n) | (v << (32 - n))) & M32
+                    hs, hprev, ws, wprev = [], [], [], []
+                    for kk in range(8):
+                        hs.append(self._mem_word(a1 + 4 * kk))
+                        hprev.append(self.mem_t.get(a1 + 4 * kk, (0, 0)))
+                        self.mem_t[a1 + 4 * kk] = (shard, clk + 2)
+                    for kk in range(64):
+                        ws.append(self._mem_word(c + 4 * kk))
+                        wprev.append(self.mem_t.get(c + 4 * kk, (0, 0)))
+                        self.mem_t[c + 4 * kk] = (shard, clk + 2)
+                    v = list(hs)
+                    for i in range(64):
+                        S1 = rotr(v[4], 6) ^ rotr(v[4], 11) ^ rotr(v[4], 25)
+                        chv = (v[4] & v[5]) ^ (~v[4] & v[6] & M32)
+                        t1 = (v[7] + S1 + chv + SHA_K[i] + ws[i]) & M32
+                        S0 = rotr(v[0], 2) ^ rotr(v[0], 13) ^ rotr(v[0], 22)
+                        mj = (v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2])
+                        v = [(t1 + S0 + mj) & M32, v[0], v[1], v[2], (v[3] + t1) & M32, v[4], v[5], v[6]]
+                    for kk in range(8):
+                        self.mem[a1 + 4 * kk] = (hs[kk] + v[kk]) & M32
+                        self.mem_t[a1 + 4 * kk] = (shard, clk + 3)
+                    cur["sha_cmp"].append(dict(clk=clk, w_ptr=c, h_ptr=a1, w=ws, hs=hs, wprev=wprev, hprev=hprev))
                 elif b == 0x1A:
                     pass
                 elif b == 0xF0:
@@ -752,6 +790,65 @@ def traces(run: Run, pos: int):
                 if j == 0:
                     lk.add(B_ADDR, byts(ev["ptr"])[0], byts(ev["ptr"])[3])
         out["sha_extend"] = mat
+
+    # ---- sha_compress: 80 rows per call (group 0 loads the state, groups 1..8 are the rounds, group 9 writes back)
+    if sh["sha_cmp"]:
+        cid, chip = chips["sha_compress"]
+        mat = np.zeros((chip.main_width, 1 << log2ceil(80 * len(sh["sha_cmp"]))), np.int64)
+        rotr = lambda v, n: ((v >> n) | (v << (32 - n))) & M32
+        bits = lambda v: [(v >> t) & 1 for t in range(32)]
+        halves = lambda v: [v & 0xFFFF, v >> 16]
+        for e, ev in enumerate(sh["sha_cmp"]):
+            v = [0] * 8                                   # a..h at the start of the row
+            for j in range(80):
+                g, o = divmod(j, 8)
+                put, putv = _col_setter(chip, mat, 80 * e + j)
+                put("is_real", 1); put("is_first", int(j == 0)); put("is_last", int(j == 79))
+                putv("oc", [int(t == o) for t in range(8)]); putv("gr", [int(t == g) for t in range(10)])
+                put("clk", ev["clk"]); putv("wp", byts(ev["w_ptr"])); putv("hp", byts(ev["h_ptr"]))
+                putv("ab", bits(v[0])); putv("bb", bits(v[1])); putv("cb", bits(v[2]))
+                putv("eb", bits(v[4])); putv("fb", bits(v[5])); putv("gb", bits(v[6]))
+                putv("d", halves(v[3])); putv("h", halves(v[7]))
+                S1 = rotr(v[4], 6) ^ rotr(v[4], 11) ^ rotr(v[4], 25)
+                S0 = rotr(v[0], 2) ^ rotr(v[0], 13) ^ rotr(v[0], 22)
+                mj = (v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2])
+                chv = (v[4] & v[5]) ^ (~v[4] & v[6] & M32)
+                putv("s1", halves(S1)); putv("s0", halves(S0)); putv("mj", halves(mj))
+                ts = ev["clk"] + 2
+                if g == 0:
+                    addr, before, prev = ev["h_ptr"] + 4 * (7 - o), ev["hs"][7 - o], ev["hprev"][7 - o]
+                    after, nxt_a, nxt_e = before, before, v[3]
+                elif g <= 8:
+                    i = 8 * (g - 1) + o
+                    addr, before, prev = ev["w_ptr"] + 4 * i, ev["w"][i], ev["wprev"][i]
+                    after = before
+                    terms = [v[7], S1, chv, SHA_K[i], before]
+                    lo_t, hi_t = sum(t & 0xFFFF for t in terms), sum(t >> 16 for t in terms)
+                    e_lo = lo_t + (v[3] & 0xFFFF); e_hi = hi_t + (v[3] >> 16) + (e_lo >> 16)
+                    a_lo = lo_t + (S0 & 0xFFFF) + (mj & 0xFFFF); a_hi = hi_t + (S0 >> 16) + (mj >> 16) + (a_lo >> 16)
+                    putv("ce", [(e_lo >> 16 >> t) & 1 for t in range(3)] + [(e_hi >> 16 >> t) & 1 for t in range(3)])
+                    putv("ca", [(a_lo >> 16 >> t) & 1 for t in range(3)] + [(a_hi >> 16 >> t) & 1 for t in range(3)])
+                    nxt_e = (e_lo & 0xFFFF) | ((e_hi & 0xFFFF) << 16)
+                    nxt_a = (a_lo & 0xFFFF) | ((a_hi & 0xFFFF) << 16)
+                    t1 = sum(terms) & M32
+                    assert nxt_e == (v[3] + t1) & M32 and nxt_a == (t1 + S0 + mj) & M32
+                else:
+                    addr, before, prev = ev["h_ptr"] + 4 * (7 - o), ev["hs"][7 - o], (sh["index"], ev["clk"] + 2)
+                    after, ts = (before + v[7]) & M32, ev["clk"] + 3
+                    lo = (before & 0xFFFF) + (v[7] & 0xFFFF)
+                    putv("cf", [lo >> 16, ((before >> 16) + (v[7] >> 16) + (lo >> 16)) >> 16])
+                    lk.add(B_RANGE, byts(after)[0], byts(after)[1]); lk.add(B_RANGE, byts(after)[2], byts(after)[3])
+                    nxt_a, nxt_e = 0, v[3]
+                put("maddr", addr); putv("mv", byts(after)); putv("mo", byts(before))
+                psh, pts = prev
+                dgap = ts - pts - 1 if psh == sh["index"] else sh["index"] - psh - 1
+                put("m_sh", psh); put("m_ts", pts); put("m_same", int(psh == sh["index"]))
+                put("m_lo", dgap & 0xFFFF); put("m_hi", dgap >> 16)
+                lk.add(B_U16, dgap & 0xFFFF); lk.add(B_RANGE, dgap >> 16, 0)
+                if j == 0:
+                    lk.add(B_ADDR, byts(ev["w_ptr"])[0], byts(ev["w_ptr"])[3]); lk.add(B_ADDR, byts(ev["h_ptr"])[0], byts(ev["h_ptr"])[3])
+                v = [nxt_a, v[0], v[1], v[2], nxt_e, v[4], v[5], v[6]]
+        out["sha_compress"] = mat
 
     # ---- preprocessed chips and their multiplicity columns
     cidp, chipp = chips["program"]

@@ -331,6 +331,44 @@ def sha_extend(blocks=2, a1=0, ptr_off=0):
     return a.elf(), b"".join(struct.pack("<I", v) for v in exp)
 
 
+SYS_SHA_COMPRESS = 0x00010106
+
+
+def sha256_precompiled(msg: bytes = bytes(range(150)), w_off=0, h_off=0):
+    """SHA-256 of `msg` with SP1's two SHA precompiles, the way the reference's guests hash through the patched `sha2`
+    crate (crates/dkg/Cargo.toml:22): per 64-byte block, SHA_EXTEND(w) then SHA_COMPRESS(w, state).  The padded message
+    sits in the data segment as big-endian words.  Returns (elf, expected result bytes = the eight state words): they go to
+    fd 1, their checksum() to the public values.  w_off / h_off move the pointers (invalid calls trap)."""
+    import hashlib
+
+    padded = msg + b"\x80" + b"\0" * ((55 - len(msg)) % 64) + struct.pack(">Q", 8 * len(msg))
+    words = list(struct.unpack(">%dI" % (len(padded) // 4), padded))
+    a = Asm()
+    src = a.dword("msg", words + [0])
+    w = a.dword("w", [0] * 68)
+    st = a.dword("state", [0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19, 0, 0, 0, 0])
+    a.li("s3", src)
+    a.li("s4", len(words) // 16)
+    a.label("block")
+    a.li("s2", w)
+    for i in range(16):
+        a.lw("a5", "s3", 4 * i)
+        a.sw("a5", "s2", 4 * i)
+    a.li("a0", w + w_off)
+    a.li("a1", 0)
+    a.li("t0", SYS_SHA_EXTEND)
+    a.ecall()
+    a.li("a0", w + w_off)
+    a.li("a1", st + h_off)
+    a.li("t0", SYS_SHA_COMPRESS)
+    a.ecall()
+    a.addi("s3", "s3", 64)
+    a.addi("s4", "s4", -1)
+    a.bne("s4", "zero", "block")
+    _finish(a, st, 32)
+    return a.elf(), b"".join(struct.pack("<I", v) for v in struct.unpack(">8I", hashlib.sha256(msg).digest()))
+
+
 def commit_only(payload=b""):
     """The SP1 exit path alone: WRITE `payload` (a multiple of 4 bytes, from the data segment) to fd 3, hash it, COMMIT the
     eight digest words, HALT(0)."""

@@ -76,7 +76,7 @@ def _encshare_case():
 
 
 @pytest.mark.parametrize("log_shard,which", [(21, "bignum"), (8, "bignum"), (9, "shifts"), (10, "muldiv"), (16, "encshare"),
-                                             (21, "sha_extend"), (9, "sha_extend")])
+                                             (21, "sha_extend"), (9, "sha_extend"), (21, "sha256_precompiled"), (10, "sha256_precompiled")])
 def test_rv32_proof_bytes_equal_oracle(log_shard, which):
     from dvt_circuits_amd import capi
 

@@ -74,7 +74,7 @@ def test_bignum_and_hint_guests(gpu):
     gpu.pk_free(pk)
 
 
-@pytest.mark.parametrize("which", ["subword", "shifts", "muldiv", "sha_extend"])
+@pytest.mark.parametrize("which", ["subword", "shifts", "muldiv", "sha_extend", "sha256_precompiled"])
 def test_subword_and_shift_guest_proofs(gpu, which):
     from dvt_circuits_amd import capi
 

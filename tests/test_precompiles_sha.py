@@ -1,7 +1,7 @@
-"""CPU tests (no GPU) of the SHA_EXTEND precompile (SP1 syscall 0x00_30_01_05, the call the
-reference's guests make through the patched `sha2` crate, crates/dkg/Cargo.toml:22): executor semantics, the sha_extend
-chip's traces against the generated checker and the LogUp multiset, the independent model, per-cell soundness of the chip
-and of the cpu chip's precompile row, and the calls that must trap."""
+"""CPU tests (no GPU) of the SHA-256 precompiles (SP1 syscalls SHA_EXTEND 0x00_30_01_05 and
+SHA_COMPRESS 0x00_01_01_06, the calls the reference's guests make through the patched `sha2` crate,
+crates/dkg/Cargo.toml:22): executor semantics against hashlib, the chips' traces against the generated checker and the
+LogUp multiset, per-cell soundness of both chips and of the cpu chip's precompile row, and the calls that must trap."""
 import os
 import re
 import struct
@@ -137,3 +137,68 @@ def test_the_cpu_row_of_a_precompile_call_is_pinned(air):
     # u[2] = 1 / (code byte 1 - 1) and u[5] .. are inverses multiplied by zero or unused decodings; u[22], u[23] only enter the
     # address expression together with u[0] (any of them can absorb a change of another: the EXPRESSION is pinned)
     assert free <= {"u_2", "u_24", "u_25"}, sorted(free)
+
+
+# ------------------------------------------------------------------------------------------------ SHA_COMPRESS
+@pytest.mark.parametrize("msg,log_shard", [(b"abc", 0), (bytes(range(200)), 0), (bytes(range(130)), 10)])
+def test_sha256_through_both_precompiles_equals_hashlib_and_satisfies_the_air(air, msg, log_shard):
+    elf, want = guests.sha256_precompiled(msg)            # want = hashlib.sha256(msg) as eight words
+    rc, rep, pv, out, err = capi.execute_io(elf)
+    assert rc == 0 and rep["halted"] and not rep["unprovable"], err
+    assert out == want and pv == guests.checksum(want)
+    chips, pubs = check_traces(air, elf, log_shard=log_shard)
+    if log_shard == 0:
+        blocks = (len(msg) + 9 + 63) // 64
+        cmp_ = next(c for c in chips if air.chip(c["chip_id"]).name == b"sha_compress")
+        col = {n: i for i, n in _names("SHA_COMPRESS").items()}
+        assert int(cmp_["main"][col["is_real"]].sum()) == 80 * blocks and int(cmp_["main"][col["is_first"]].sum()) == blocks
+
+
+def test_invalid_compress_calls_trap():
+    for kw, frag in ((dict(h_off=2), "misaligned"), (dict(w_off=1), "misaligned"), (dict(h_off=0x38000000), "out of range")):
+        rc, rep, _, err = capi.execute(guests.sha256_precompiled(b"abc", **kw)[0])
+        assert rc != 0 and frag in err, (kw, err)
+    # state inside the schedule array: the same word would be accessed twice at one timestamp
+    elf, _ = guests.sha256_precompiled(b"abc")
+    from tools.rvasm import Asm
+
+    a = Asm()
+    w = a.dword("w", [0] * 80)
+    for ptr_w, ptr_h in ((w, w + 64), (w + 16, w)):
+        a2 = Asm()
+        w2 = a2.dword("w", [0] * 80)
+        a2.li("a0", w2 + (ptr_w - w)); a2.li("a1", w2 + (ptr_h - w)); a2.li("t0", guests.SYS_SHA_COMPRESS); a2.ecall(); a2.halt(0)
+        rc, rep, _, err = capi.execute(a2.elf())
+        assert rc != 0 and "overlap" in err, err
+
+
+def test_every_cell_of_the_compress_chip_is_pinned(air):
+    """single-cell changes on a state-load row, round rows and a write-back row of the second call of a two-block hash:
+    every one breaks a constraint or the LogUp balance, except cells the row does not use"""
+    elf, want = guests.sha256_precompiled(bytes(range(70)))
+    chips, pubs, _ = capi.rv32_debug_traces(elf)
+    extra = pv_extra(guests.checksum(want))
+    assert air.logup_unbalanced(chips, pubs, extra=extra)[0] == 0
+    cmp_ = next(c for c in chips if air.chip(c["chip_id"]).name == b"sha_compress")
+    names = _names("SHA_COMPRESS")
+    main = cmp_["main"]
+    carries = {f"c{t}_{i}" for t in "ea" for i in range(6)}
+    for row in (0, 5, 8, 9, 40, 71, 72, 79, 80 + 3, 80 + 30, 80 + 76):
+        free = set()
+        for c in range(main.shape[0]):
+            m = main.copy()
+            m[c, row] = (int(m[c, row]) + 1) % P
+            if air.check_constraints(cmp_["chip_id"], m, cmp_["prep"], pubs)[0]:
+                continue
+            if air.logup_unbalanced([dict(cmp_, main=m) if ch is cmp_ else ch for ch in chips], pubs, extra=extra)[0]:
+                continue
+            free.add(names[c])
+        g = (row % 80) // 8
+        allowed = set()
+        if g == 0 or g == 9:
+            allowed |= carries                      # no addition on these rows
+        if g != 9:
+            allowed |= {"cf_0", "cf_1"}
+        if row % 80 == 0:
+            allowed |= {"h_0", "h_1"}               # the variables of a call's first row are shifted out before any use
+        assert free <= allowed, (row, sorted(free - allowed))

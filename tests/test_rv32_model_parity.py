@@ -30,6 +30,8 @@ def cases():
         "commit_only": (guests.commit_only(b"public-values"[:12]), (), 21),
         "sha_extend": (guests.sha_extend()[0], (), 21),
         "sha_extend_sharded": (guests.sha_extend(3)[0], (), 10),
+        "sha256_precompiled": (guests.sha256_precompiled(bytes(range(150)))[0], (), 21),
+        "sha256_precompiled_sharded": (guests.sha256_precompiled(bytes(range(150)))[0], (), 10),
         "encshare_n3": (guests.dkg_like("encshare"), [enc], 15),
     }
 

@@ -13,6 +13,7 @@ Chips
   shift     SLL/SRL/SRA rows, fed by the cpu chip over the alu bus (only in shards that shift)
   muldiv    MULH/MULHSU/DIV/DIVU/REM/REMU rows, same bus (only in shards that use them)
   sha_extend  the SHA_EXTEND precompile (SHA-256 message schedule, 64 rows per call), fed over the sys bus
+  sha_compress  the SHA_COMPRESS precompile (SHA-256 compression function, 80 rows per call), same bus
 
 Memory consistency is an offline-checking LogUp multiset over tuples
 (addr, byte0..3, timestamp): every access consumes the previous tuple of its
@@ -38,6 +39,14 @@ ALU_MULH, ALU_MULHSU, ALU_DIV, ALU_DIVU, ALU_REM, ALU_REMU = 4, 5, 6, 7, 8, 9
 SYS_COMMIT = 0x10
 SYS_HINT_LEN = 0xF0
 SYS_SHA_EXTEND = 0x00300105     # SP1's syscall code: byte 0 = id, byte 1 = 1 "has a precompile table", byte 2 = extra cycles
+SYS_SHA_COMPRESS = 0x00010106
+SHA_K = [
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2]
 REG_A1 = 11
 
 # byte-table opcodes
@@ -665,6 +674,136 @@ def build_sha_extend():
     return ch
 
 
+def build_sha_compress():
+    """SHA_COMPRESS precompile (SP1 syscall 0x00_01_01_06, a0 = pointer to the 64 schedule words, a1 = pointer to the
+    8 state words): the SHA-256 compression function, state updated in place.
+    80 rows per call, row j = 8 g + o (group g = 0..9, position o = 0..7 as one-hot flags):
+      g = 0      row o READS state word 7 - o into the working variable a,
+      g = 1..8   round i = 8 (g - 1) + o: READS w[i]; a' = T1 + T2, e' = d + T1,
+      g = 9      row o does state[7 - o] += h (read-modify-write, one timestamp later than the reads).
+    On EVERY row the working variables rotate a -> b -> ... -> h, so the eight loaded words line up as (a, ..., h) after
+    group 0 and pass through h, in the order 7, 6, ..., 0, in group 9.  a, b, c, e, f, g are kept as bits (Sigma / Ch / Maj), d and
+    h as 16-bit halves.  One memory access per row: the reads at (shard, clk + 2) of the ECALL, the write-back at clk + 3."""
+    ch = Chip("sha_compress")
+    shard = ch.pub(PUB_SHARD)
+    is_real, is_first = ch.col("is_real"), ch.col("is_first")
+    oc, gr = ch.cols("oc", 8), ch.cols("gr", 10)
+    clk = ch.col("clk")
+    wp, hp = ch.cols("wp", 4), ch.cols("hp", 4)
+    A, Bb, Cc = ch.cols("ab", 32), ch.cols("bb", 32), ch.cols("cb", 32)
+    E, Fb, G = ch.cols("eb", 32), ch.cols("fb", 32), ch.cols("gb", 32)
+    d, h = ch.cols("d", 2), ch.cols("h", 2)
+    S1, S0, MJ = ch.cols("s1", 2), ch.cols("s0", 2), ch.cols("mj", 2)
+    ce, ca, cf = ch.cols("ce", 6), ch.cols("ca", 6), ch.cols("cf", 2)      # carries of e' (3 bits per half), a', the write-back
+    maddr = ch.col("maddr")
+    mv, mo = ch.cols("mv", 4), ch.cols("mo", 4)          # memory word after / before the access
+    m_sh, m_ts, m_same, m_lo, m_hi = ch.col("m_sh"), ch.col("m_ts"), ch.col("m_same"), ch.col("m_lo"), ch.col("m_hi")
+    nr = is_real.next()
+    is_init, is_fin = gr[0], gr[9]
+    is_round = esum(gr[1:9])
+    is_last = ch.col("is_last")
+    # ---- row structure: position and group one-hot, position advances every row, group when position wraps
+    for f in [is_real, is_first, is_last] + oc + gr:
+        ch.assert_bool(f)
+    ch.assert_eq(esum(oc), is_real)
+    ch.assert_eq(esum(gr), is_real)
+    ch.assert_zero(nr * (1 - is_real), "trans")
+    ch.assert_eq(is_first, is_real, "first")
+    ch.assert_zero(is_first - gr[0] * oc[0])
+    ch.assert_zero(is_last - gr[9] * oc[7])
+    ch.assert_zero(nr * (is_first.next() - is_last), "trans")        # a call starts right after the previous one ends
+    ch.assert_zero((is_real - nr) * (1 - is_last), "trans")          # ... and the table ends with a complete call
+    ch.assert_zero(is_real * (1 - is_last), "last")
+    inner = is_real - is_last
+    for o in range(8):
+        ch.assert_zero(nr * (oc[(o + 1) % 8].next() - oc[o]), "trans")
+    # (no gating by "the next row is real": group 0 is entered through the next row's is_first, not by wrapping from
+    #  group 9, so the equations also hold from the last call into the padding, where every flag is 0)
+    ch.assert_zero(gr[0].next() - gr[0] * (1 - oc[7]) - is_first.next(), "trans")
+    for g in range(1, 10):
+        ch.assert_zero(gr[g].next() - gr[g] * (1 - oc[7]) - gr[g - 1] * oc[7], "trans")
+    ch.assert_zero(inner * (clk.next() - clk), "trans")
+    for i in range(4):
+        ch.assert_zero(inner * (wp[i].next() - wp[i]), "trans")
+        ch.assert_zero(inner * (hp[i].next() - hp[i]), "trans")
+    # ---- the call from the cpu chip; both pointers word-aligned and below 0x38000000
+    code = [(SYS_SHA_COMPRESS >> (8 * i)) & 0xFF for i in range(4)]
+    ch.receive("sys", code + wp + hp + [clk, shard], is_first)
+    ch.send("byte", [B_ADDR, 0, wp[0], wp[3]], is_first)
+    ch.send("byte", [B_ADDR, 0, hp[0], hp[3]], is_first)
+    # ---- bits
+    for t in A + Bb + Cc + E + Fb + G + ce + ca + cf:
+        ch.assert_bool(t)
+
+    def halves(bits):
+        return [esum((1 << k) * bits[16 * hh + k] for k in range(16)) for hh in range(2)]
+
+    def xor3(a, b_, c_):
+        return a + b_ + c_ - 2 * (a * b_ + a * c_ + b_ * c_) + 4 * (a * b_ * c_)
+
+    def rot3(bits, r1, r2, r3):
+        return [xor3(bits[(k + r1) % 32], bits[(k + r2) % 32], bits[(k + r3) % 32]) for k in range(32)]
+
+    sig1, sig0 = rot3(E, 6, 11, 25), rot3(A, 2, 13, 22)
+    maj = [A[k] * Bb[k] + A[k] * Cc[k] + Bb[k] * Cc[k] - 2 * (A[k] * Bb[k] * Cc[k]) for k in range(32)]
+    chh = [E[k] * Fb[k] + (1 - E[k]) * G[k] for k in range(32)]            # degree 2: used inline
+    for hh in range(2):
+        ch.assert_eq(S1[hh], halves(sig1)[hh])
+        ch.assert_eq(S0[hh], halves(sig0)[hh])
+        ch.assert_eq(MJ[hh], halves(maj)[hh])
+    CH = halves(chh)
+    # round constant of this row: K[8 (g - 1) + o] on round rows
+    K = [esum(gr[g] * esum(oc[o] * ((SHA_K[8 * (g - 1) + o] >> (16 * hh)) & 0xFFFF) for o in range(8)) for g in range(1, 9)) for hh in range(2)]
+    x = [mv[0] + 256 * mv[1], mv[2] + 256 * mv[3]]                         # the word this row reads (state word or w[i])
+    xo = [mo[0] + 256 * mo[1], mo[2] + 256 * mo[3]]
+    # ---- rotation of the working variables (every row of a call but its last)
+    an, en = halves([t.next() for t in A]), halves([t.next() for t in E])
+    for k in range(32):
+        ch.assert_zero(inner * (Bb[k].next() - A[k]), "trans")
+        ch.assert_zero(inner * (Cc[k].next() - Bb[k]), "trans")
+        ch.assert_zero(inner * (Fb[k].next() - E[k]), "trans")
+        ch.assert_zero(inner * (G[k].next() - Fb[k]), "trans")
+    hc, hg = halves(Cc), halves(G)
+    for hh in range(2):
+        ch.assert_zero(inner * (d[hh].next() - hc[hh]), "trans")
+        ch.assert_zero(inner * (h[hh].next() - hg[hh]), "trans")
+    # e' = d + T1 on round rows, e' = d otherwise;  T1 = h + Sigma1(e) + Ch(e, f, g) + K + w
+    # a' = T1 + T2 on round rows, a' = the word read on load rows (free in the write-back group); T2 = Sigma0(a) + Maj(a, b, c)
+    # (is_round x the degree-2 Ch / K expressions is degree 3, so these equations carry no transition selector: they hold on
+    #  every row, the cyclic last -> first one included, because the table's last row is padding or a call's last row and
+    #  is_round = is_init = 0 there)
+    ce_lo, ce_hi = ce[0] + 2 * ce[1] + 4 * ce[2], ce[3] + 2 * ce[4] + 4 * ce[5]
+    ca_lo, ca_hi = ca[0] + 2 * ca[1] + 4 * ca[2], ca[3] + 2 * ca[4] + 4 * ca[5]
+    t1 = [h[hh] + S1[hh] + x[hh] for hh in range(2)]                       # the linear part of T1
+    ch.assert_zero(is_round * (t1[0] + CH[0] + K[0] + d[0] - en[0] - 65536 * ce_lo) + is_init * (d[0] - en[0]))
+    ch.assert_zero(is_round * (t1[1] + CH[1] + K[1] + d[1] + ce_lo - en[1] - 65536 * ce_hi) + is_init * (d[1] - en[1]))
+    ch.assert_zero(is_round * (t1[0] + CH[0] + K[0] + S0[0] + MJ[0] - an[0] - 65536 * ca_lo) + is_init * (x[0] - an[0]))
+    ch.assert_zero(is_round * (t1[1] + CH[1] + K[1] + S0[1] + MJ[1] + ca_lo - an[1] - 65536 * ca_hi) + is_init * (x[1] - an[1]))
+    ch.assert_zero((is_fin - is_last) * (d[0] - en[0]), "trans")
+    ch.assert_zero((is_fin - is_last) * (d[1] - en[1]), "trans")
+    # ---- write-back group: state[7 - o] = old + h  (mod 2^32)
+    ch.assert_zero(is_fin * (xo[0] + h[0] - x[0] - 65536 * cf[0]))
+    ch.assert_zero(is_fin * (xo[1] + h[1] + cf[0] - x[1] - 65536 * cf[1]))
+    ch.send("byte", [B_RANGE, 0, mv[0], mv[1]], is_fin)
+    ch.send("byte", [B_RANGE, 0, mv[2], mv[3]], is_fin)
+    for i in range(4):
+        ch.assert_zero((is_real - is_fin) * (mv[i] - mo[i]))                # reads leave memory unchanged
+    # ---- the row's memory access
+    pos = esum(o * oc[o] for o in range(8))
+    rnd = 8 * esum((g - 1) * gr[g] for g in range(1, 9)) + pos          # round index on round rows
+    ch.assert_zero(maddr - is_round * (word(wp) + 4 * rnd) - (is_init + is_fin) * (word(hp) + 28 - 4 * pos))
+    ts = clk + 2 + is_fin
+    ch.receive("mem", [maddr] + mo + [m_sh, m_ts], is_real)
+    ch.send("mem", [maddr] + mv + [shard, ts], is_real)
+    ch.assert_zero(is_real * (m_same * (m_same - 1)))
+    ch.assert_zero(is_real * (m_same * (shard - m_sh)))
+    ch.assert_zero(is_real * (m_same * (ts - m_ts - 1) + (1 - m_same) * (shard - m_sh - 1) - m_lo - 65536 * m_hi))
+    ch.send("byte", [B_U16, 0, m_lo, 0], is_real)
+    ch.send("byte", [B_RANGE, 0, m_hi, 0], is_real)
+    ch.quotient_parts = 3
+    return ch
+
+
 def build_mem_image():
     ch = Chip("mem_image")
     addr, v, real = ch.prep("addr"), ch.preps("v", 4), ch.prep("is_real")
@@ -708,4 +847,4 @@ def build_mem_init():
 
 def build():
     return Machine("rv32", [build_program(), build_byte(), build_cpu(), build_mem_image(), build_mem_init(), build_shift(), build_muldiv(),
-                            build_sha_extend()], BUSES)
+                            build_sha_extend(), build_sha_compress()], BUSES)
