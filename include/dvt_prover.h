@@ -152,7 +152,9 @@ int dvt_setup(dvt_prover *p, const uint8_t *elf, size_t elf_len, dvt_pk **pk, ui
  * Guest syscall ABI (SP1's): t0 = id, a0..a2 = arguments: 0x00 HALT(code),
  * 0x02 WRITE(fd, ptr, len), 0x10 COMMIT(index, word) - the eight words of SHA-256(public-value bytes),
  * which the proof binds -, 0x1A COMMIT_DEFERRED_PROOFS (no-op), 0xF0 HINT_LEN, 0xF1 HINT_READ(ptr, len).
- * Precompile syscalls (SHA-256 / BLS12-381 / secp256k1 accelerators) are not implemented: the guest traps. */
+ * Precompiles (SP1 syscall codes with byte 1 = 1, proven by their own chips): 0x00_30_01_05 SHA_EXTEND(w) and
+ * 0x00_01_01_06 SHA_COMPRESS(w, state), the two calls of SP1's patched `sha2` crate.  The BLS12-381 / secp256k1
+ * accelerators are not implemented: such a call traps ("unknown syscall"), no proof is produced. */
 int dvt_execute(const uint8_t *elf, size_t elf_len, const dvt_buf *stdin_bufs, size_t nbuf, uint64_t max_cycles,
                 uint8_t **public_values, size_t *pv_len, dvt_report *report, char **err_text);
 /* the same, also handing back what the guest wrote to the other file descriptors (SP1 forwards fd 1 / 2 to the
