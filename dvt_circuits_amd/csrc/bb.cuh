@@ -14,7 +14,14 @@
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+// forced inlining only in the device pass: on the host it would fold a chip's whole generated verifier (thousands of F_p^4
+// operations, every operator inlined) into one function whose -O3 compile time grows quadratically (18 minutes for the
+// rv32 machine); the host compiler's own inlining heuristics are enough there
+#if defined(__HIP_DEVICE_COMPILE__)
 #define DVT_HD __host__ __device__ __forceinline__
+#else
+#define DVT_HD __host__ __device__ inline
+#endif
 #else
 #define DVT_HD inline
 #endif

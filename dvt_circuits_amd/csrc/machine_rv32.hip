@@ -1,6 +1,16 @@
 // Instantiates the generic STARK kernels for the RV32IM core machine.
 #include "machine.h"
+// The generated AIR code is instantiated twice: for the gfx950 kernels (T = Fp, device pass, fully optimised) and for the
+// host verifier (T = Fp4).  The host instantiation is thousands of F_p^4 operations of straight-line code per chip that
+// run once per proof; optimising it at -O3 (inlining every operator) took 18 of this file's 22 minutes of compile time.
+// It is compiled unoptimised instead (each F_p^4 operator stays a call).
+#if !defined(__HIP_DEVICE_COMPILE__)
+#pragma clang optimize off
+#endif
 #include "gen/air_rv32.inc"
+#if !defined(__HIP_DEVICE_COMPILE__)
+#pragma clang optimize on
+#endif
 
 namespace dvt {
 #define DVT_X(i, A) make_chip_desc<A>(),
