@@ -420,7 +420,8 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
         // in t0), u[25] 1/(id - HINT_LEN); u[1] is_pre (byte 1 of the code = 1: the call has a precompile chip), u[2] 1/(byte 1 - 1).
         // COMMIT and precompile rows ("sys rows") read a1 (x11) through the memory port and send on the sys bus; u[3] / u[21] =
         // clk / shard on precompile rows; u[0] balances the port's address expression u0 + 256 u1 + .. - (u21 + 2 u22 + 3 u23) = 11
-        uint32_t idc = b % P;
+        // the id as the AIR compares it: b0 + 256 b1 + 65536 b2 + 2^22 b3 (< p, and equal to a one-byte id only for (id, 0, 0, 0))
+        const uint32_t idc = B(b, 0) + 256u * B(b, 1) + 65536u * B(b, 2) + (B(b, 3) << 22);
         s.put(U + 24, idc == SYS_HINT_LEN);
         if (idc != SYS_HINT_LEN) s.put(U + 25, inv(Fp::from_canonical(idc) - Fp::from_canonical(SYS_HINT_LEN)).canonical());
         s.put(U + 4, idc == 0);

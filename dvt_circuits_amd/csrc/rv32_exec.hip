@@ -385,7 +385,9 @@ L_ECALL: {
     a = b;  // t0 unchanged unless the call returns a value
     nip = ip + 1;
     switch (b) {
-    case 0x00: halted = true; exit_code = (int)c; break;
+    case 0x00:
+        if (c >> 24) { why = "HALT with an exit code of 2^24 or more"; goto trapped; }
+        halted = true; exit_code = (int)c; break;
     case 0x02: {  // WRITE(fd = a0, ptr = a1, len = a2): fd 3 = the public-value stream
         if ((uint64_t)a1 + a2 > ADDR_LIMIT) { why = "WRITE buffer out of range"; goto trapped; }
         if (!collect_output) break;

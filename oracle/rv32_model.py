@@ -306,6 +306,8 @@ class Run:
                 a = b
                 a1, a2 = self.reg[11], self.reg[12]
                 if b == 0x00:
+                    if c >> 24:
+                        raise Trap("HALT with an exit code of 2^24 or more at pc 0x%x" % pc)
                     self.halted, self.exit_code, nxt = True, sx(c), 0
                 elif b == 0x02:
                     if a1 + a2 > ADDR_LIMIT:
@@ -593,7 +595,7 @@ def traces(run: Run, pos: int):
             U[19], U[10], U[20] = 1, byts(a)[3], 0x78
             lk.add(B_LTU, byts(a)[3], 0x78)
         elif k == "ecall":
-            sid = b % P
+            sid = byts(b)[0] + 256 * byts(b)[1] + 65536 * byts(b)[2] + (byts(b)[3] << 22)   # the id as the AIR compares it
             U[24] = int(sid == 0xF0)                               # HINT_LEN: the one call whose return value is advice
             U[25] = 0 if sid == 0xF0 else inv(sid - 0xF0)
             U[4] = int(sid == 0)

@@ -384,3 +384,25 @@ def test_empty_public_values_commit_the_golden_digest_words():
     for k, r in enumerate(rows):
         assert sum(int(cpu[col[f"c_{i}"], r]) << (8 * i) for i in range(4)) == k
         assert sum(int(cpu[col[f"u_{9 + i}"], r]) << (8 * i) for i in range(4)) == golden[k]
+
+
+def test_syscall_id_and_exit_code_are_compared_as_integers_not_mod_p(air):
+    """t0 = p (bytes 01 00 00 78) is congruent to the HALT id 0 and a0 = p to the exit code 0: a row forged that way (the
+    executor would trap on it as an unknown syscall) must not satisfy the ECALL constraints — the id is compared through a
+    byte combination that cannot wrap, the exit code is below 2^24"""
+    P = 2013265921
+    elf, _ = guests.arith(commit=False)
+    chips, pubs, _ = capi.rv32_debug_traces(elf)
+    cpu = next(c for c in chips if air.chip(c["chip_id"]).name == b"cpu")
+    col = {n: i for i, n in _cpu_names().items()}
+    main = cpu["main"]
+    row = max(r for r in range(main.shape[1]) if main[col["is_ecall"], r] == 1)
+    assert main[col["u_4"], row] == 1 and pubs[2] == 0                      # the HALT row, exit code 0
+    assert air.check_constraints(cpu["chip_id"], main, cpu["prep"], pubs)[0] == 0
+    for reg in ("b", "c"):
+        m = main.copy()
+        for i, v in enumerate(P.to_bytes(4, "little")):
+            m[col[f"{reg}_{i}"], row] = v
+        assert air.check_constraints(cpu["chip_id"], m, cpu["prep"], pubs)[0] > 0, reg
+    rc, rep, _, err = capi.execute(guests.exit_with(1 << 24))
+    assert rc != 0 and "exit code" in err

@@ -357,19 +357,24 @@ def build_cpu():
 
     # ECALL: b = t0 (syscall id), c = a0; a = new t0 (advice).  id 0 = HALT(exit code a0).
     # (witness cells in u[4..7]: u[0..3] hold the address bytes of the a1 read of COMMIT rows)
+    # The call id is compared through idw = b0 + 256 b1 + 65536 b2 + 2^22 b3 (at most 1.09e9 < p: no reduction mod p), NOT
+    # through word(b): t0 = id + p is a valid 32-bit value that word(b) cannot tell from id.  For a target id below 2^8,
+    # idw = id holds only for the bytes (id, 0, 0, 0): the higher terms are multiples of 256 and b0 - id lies in (-256, 256).
+    idw = b[0] + 256 * b[1] + 65536 * b[2] + (1 << 22) * b[3]
     is_halt, id_inv = U[4], U[5]
     ec = F["is_ecall"]
     ch.assert_zero(ec * (is_halt * (is_halt - 1)))
-    ch.assert_zero(ec * (is_halt * word(b)))
-    ch.assert_zero(ec * (word(b) * id_inv - (1 - is_halt)))
+    ch.assert_zero(ec * (is_halt * idw))
+    ch.assert_zero(ec * (idw * id_inv - (1 - is_halt)))
     ch.assert_zero(ec * (next_pc - (1 - is_halt) * (pc + 4)))
     ch.assert_zero(ec * (is_halt * (word(c) - ch.pub(PUB_EXIT_CODE))))
+    ch.assert_zero(ec * (is_halt * c[3]))        # exit codes are below 2^24: word(c) is the exit code itself, not a residue
     # only HINT_LEN (id 0xF0) returns a value in t0 (advice: the length of the next stdin buffer, private input like the
     # buffer itself); every other call leaves t0 unchanged.  u[24] = "is HINT_LEN", u[25] = 1 / (id - 0xF0)
     is_hl, hl_inv = U[24], U[25]
     ch.assert_zero(ec * (is_hl * (is_hl - 1)))
-    ch.assert_zero(ec * (is_hl * (word(b) - SYS_HINT_LEN)))
-    ch.assert_zero(ec * ((word(b) - SYS_HINT_LEN) * hl_inv - (1 - is_hl)))
+    ch.assert_zero(ec * (is_hl * (idw - SYS_HINT_LEN)))
+    ch.assert_zero(ec * ((idw - SYS_HINT_LEN) * hl_inv - (1 - is_hl)))
     for i in range(4):
         ch.assert_zero(ec * ((1 - is_hl) * (a[i] - b[i])))
     # COMMIT (id 0x10, a0 = index, a1 = word) — SP1's syscall contract: the guest hashes the bytes
@@ -386,8 +391,8 @@ def build_cpu():
     # u[3] u_clk, u[21] u_sh; u[0] balances the address expression.
     is_commit, cm_inv = U[6], U[7]
     ch.assert_zero(ec * (is_commit * (is_commit - 1)))
-    ch.assert_zero(ec * (is_commit * (word(b) - SYS_COMMIT)))
-    ch.assert_zero(ec * ((word(b) - SYS_COMMIT) * cm_inv - (1 - is_commit)))
+    ch.assert_zero(ec * (is_commit * (idw - SYS_COMMIT)))
+    ch.assert_zero(ec * ((idw - SYS_COMMIT) * cm_inv - (1 - is_commit)))
     is_pre, pre_inv, u_clk, u_sh = U[1], U[2], U[3], U[21]
     ch.assert_zero(ec * (is_pre * (is_pre - 1)))
     ch.assert_zero(ec * (is_pre * (b[1] - 1)))
