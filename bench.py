@@ -65,6 +65,9 @@ def workload_stdin(participants=0, instance=None):
     return capi.stdin_from_json("finalization", json.dumps(doc).encode())
 
 
+SHA_PRECOMPILES = False   # --sha-precompiles
+
+
 def fit_constants(stdin_buf, total_shards, sig=0):
     """iteration constants (sig, pt, pair) of the guest so that the execution fills total_shards shards of 2^21 cycles
     as closely as possible from below (pt = sig / 4: the reference's per-key work is a fraction of its pairing work)"""
@@ -73,7 +76,7 @@ def fit_constants(stdin_buf, total_shards, sig=0):
 
     def cycles(s):
         c = (s, max(1, s // 4), 1)
-        return capi.execute(guests.dkg_like("finalization", *c), [stdin_buf])[1]["cycles"], c
+        return capi.execute(guests.dkg_like("finalization", *c, sha_precompiles=SHA_PRECOMPILES), [stdin_buf])[1]["cycles"], c
 
     if sig:
         return cycles(sig)[1]
@@ -127,10 +130,14 @@ def main():
                     "input of the same format (tools/gen_dkg_input.py), e.g. 255")
     ap.add_argument("--batch", type=int, default=0, help="B independent single-shard proofs round-robin over the ranks instead of one sharded execution")
     ap.add_argument("--batch-streams", type=int, default=3, help="--batch: prover handles (one host thread + HIP stream each) per GPU")
+    ap.add_argument("--sha-precompiles", action="store_true", help="the guest hashes through SP1's SHA_EXTEND / SHA_COMPRESS precompile "
+                    "syscalls (sha_extend / sha_compress chips) instead of RV32IM code; not the default workload")
     ap.add_argument("--exec-threads", type=int, default=0)
     ap.add_argument("--cpu-sizes", type=int, nargs=2, default=[20, 60])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    global SHA_PRECOMPILES
+    SHA_PRECOMPILES = args.sha_precompiles
 
     import torch
 
@@ -165,7 +172,7 @@ def main():
     if args.batch:
         # ---------------------------------------------------------------- B independent proofs ("replicas only")
         consts = fit_constants(stdin_buf, 1, args.sig_iters)
-        elf = guests.dkg_like("finalization", *consts)
+        elf = guests.dkg_like("finalization", *consts, sha_precompiles=SHA_PRECOMPILES)
         pk, vk = prover.setup(elf)
         inputs = [workload_stdin(args.participants, instance=i) for i in range(args.batch)]
         mine = ranks.shard_of(args.batch)
@@ -226,7 +233,7 @@ def main():
         # ---------------------------------------------------------------- one execution, shard-parallel
         total_shards = args.shards_per_gpu * world
         consts = fit_constants(stdin_buf, total_shards, args.sig_iters)
-        elf = guests.dkg_like("finalization", *consts)
+        elf = guests.dkg_like("finalization", *consts, sha_precompiles=SHA_PRECOMPILES)
         pk, vk = prover.setup(elf)
         want_pv = guests.dkg_like_expected(stdin_buf, "finalization", *consts)
         state = {}
@@ -276,7 +283,7 @@ def main():
     #      (always on the reference's example input: an n = 255 input does not fit one shard)
     stdin_buf = workload_stdin(0)
     one = fit_constants(stdin_buf, 1)
-    elf1 = guests.dkg_like("finalization", *one)
+    elf1 = guests.dkg_like("finalization", *one, sha_precompiles=SHA_PRECOMPILES)
     pk1, _ = prover.setup(elf1)
     job1, rep1 = prover.prepare(pk1, [stdin_buf])
     prover.prove_job(pk1, job1, want_bytes=False)
@@ -331,6 +338,7 @@ def main():
             "measured_unit": "the whole boundary call: host execution of the guest + record upload + K0..K9 (reference src/main.rs:461-466)",
             "stdin_bytes": stdin_bytes,
             "participants": args.participants or 3,
+            "sha_precompiles": bool(args.sha_precompiles),
             "guest_cycles_per_step": cycles,
             "shards_per_step": n_shards,
             "shards_per_gpu": args.shards_per_gpu if not args.batch else None,

@@ -32,7 +32,9 @@ def sha_padding(nbytes):
 def emit_sha256(a):
     """SHA-256 compression in RV32IM: label `sha256_blocks`(a0 = message, already padded, a1 = number of 64-byte blocks,
     a2 = the eight state words, updated in place).  Clobbers every t, a and s register except ra / sp.  Emitted once
-    per program; its tables live in the data segment."""
+    per program; its tables live in the data segment.  With a.sha_precompiles = True the message schedule and the 64 rounds
+    of every block are SP1's SHA_EXTEND / SHA_COMPRESS precompile calls (what the patched `sha2` crate of the reference's
+    guests does, crates/dkg/Cargo.toml:22) instead of ~5 000 RV32IM cycles."""
     if "sha256_blocks" in a.labels or getattr(a, "_sha_pending", False):
         return
     a._sha_pending = True
@@ -72,6 +74,21 @@ def emit_sha256(a):
     a.sw("t0", "t6", 0)
     a.addi("s5", "s5", 4)
     a.bne("s5", "s6", "sha_ld")
+    if getattr(a, "sha_precompiles", False):
+        a.mv("a0", "s3")
+        a.li("a1", 0)
+        a.li("t0", SYS_SHA_EXTEND)
+        a.ecall()
+        a.mv("a0", "s3")
+        a.mv("a1", "s2")
+        a.li("t0", SYS_SHA_COMPRESS)
+        a.ecall()
+        a.addi("s0", "s0", 64)
+        a.addi("s1", "s1", -1)
+        a.bne("s1", "zero", "sha_block")
+        a.ret()
+        a.label("sha256_end")
+        return
     a.li("s6", 256)
     a.label("sha_ext")          # W[i] = W[i-16] + s0(W[i-15]) + W[i-7] + s1(W[i-2])
     a.add("t6", "s3", "s5")
@@ -792,7 +809,7 @@ def chacha20_block_py(state):
     return [(x[i] + state[i]) & M32 for i in range(16)]
 
 
-def dkg_like(kind="finalization", sig_iters=2, pt_iters=1, pair_iters=1):
+def dkg_like(kind="finalization", sig_iters=2, pt_iters=1, pair_iters=1, sha_precompiles=False):
     """The n-participant DKG-shaped guest (see the block comment above).  kind = "finalization" | "encshare".  The ELF
     depends only on the iteration constants; n and k come from the stdin buffer at run time.  Returns the ELF;
     dkg_like_expected() is the same computation in Python."""
@@ -801,6 +818,7 @@ def dkg_like(kind="finalization", sig_iters=2, pt_iters=1, pair_iters=1):
     assert kind in ("finalization", "encshare")
     L, L2 = DKG_L, DKG_L2
     a = Asm()
+    a.sha_precompiles = sha_precompiles
     pa, pb = a.dword("x", DKG_A), a.dword("y", DKG_B)
     pt = a.dword("t", [0] * (2 * L + 2))
     pa2, pb2 = a.dword("x2", DKG_A2), a.dword("y2", DKG_B2)

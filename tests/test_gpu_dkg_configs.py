@@ -145,6 +145,20 @@ def test_config4_concurrent_handles_reproduce_the_sequential_bytes(gpu):
     assert capi.verify(vk, got[3])[0]
 
 
+def test_finalization_guest_with_sha_precompiles(gpu):
+    """the finalization-shaped guest hashing through SHA_EXTEND / SHA_COMPRESS (as the reference's guests do through the
+    patched sha2 crate): the proof verifies with the public values of the software-SHA form"""
+    from dvt_circuits_amd import capi
+
+    buf = capi.stdin_from_json("finalization", open(os.path.join(ROOT, "tests", "golden", "finalization_example.json"), "rb").read())
+    elf = guests.dkg_like("finalization", 40, 10, 1, sha_precompiles=True)
+    pk, vk = gpu.setup(elf)
+    proof, rep = gpu.prove_core(pk, [buf])
+    ok, ec, pv, why = capi.verify(vk, proof)
+    assert ok and ec == 0 and pv == guests.dkg_like_expected(buf, "finalization", 40, 10, 1), why
+    gpu.pk_free(pk)
+
+
 def test_bench_batch_mode_line():
     """bench.py --batch (BASELINE configs[4], replicas only) end to end, small B"""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],

@@ -202,3 +202,19 @@ def test_every_cell_of_the_compress_chip_is_pinned(air):
         if row % 80 == 0:
             allowed |= {"h_0", "h_1"}               # the variables of a call's first row are shifted out before any use
         assert free <= allowed, (row, sorted(free - allowed))
+
+
+def test_dkg_shaped_guest_hashing_through_the_precompiles(air):
+    """the finalization-shaped guest with every SHA-256 block done by SHA_EXTEND + SHA_COMPRESS (the patched `sha2` crate's
+    calls) commits the same public values as its software-SHA form in fewer cycles, and its shards satisfy the AIR"""
+    import json
+
+    example = open(os.path.join(ROOT, "tests", "golden", "finalization_example.json"), "rb").read()
+    buf = capi.stdin_from_json("finalization", example)
+    want = guests.dkg_like_expected(buf, "finalization")
+    soft = capi.execute(guests.dkg_like("finalization"), [buf])
+    elf = guests.dkg_like("finalization", sha_precompiles=True)
+    rc, rep, pv, err = capi.execute(elf, [buf])
+    assert rc == 0 and pv == want == soft[2], err
+    assert rep["cycles"] < soft[1]["cycles"] // 2
+    check_traces(air, elf, [buf], log_shard=13)
