@@ -85,8 +85,8 @@ __device__ __forceinline__ uint32_t lane_block(uint32_t bw, uint32_t ell, uint32
 // Geometry: the runtime arguments (L, s, tw_shift, log_cols) serve every size; with SL >= 0 the template arguments replace
 // them, every swizzled offset below folds to a literal and only the block / row part of an address is computed at run
 // time (measured: with runtime geometry the address arithmetic of a pass costs as many VALU slots as its butterflies).
-template <int R, int SL = -1, int SS = 0, int STW = 0, int SLC = 0>
-__device__ __forceinline__ void dif_pass(Lw *sm, const Lw *tw, uint32_t L_rt, uint32_t s_rt, uint32_t tw_shift_rt, uint32_t log_cols_rt,
+template <int R, int SL = -1, int SS = 0, int STW = 0, int SLC = 0, class TW = Lw>
+__device__ __forceinline__ void dif_pass(Lw *sm, const TW *tw, uint32_t L_rt, uint32_t s_rt, uint32_t tw_shift_rt, uint32_t log_cols_rt,
                                          uint32_t tid, uint32_t nt) {
     const uint32_t L = SL >= 0 ? (uint32_t)SL : L_rt, s = SL >= 0 ? (uint32_t)SS : s_rt;
     const uint32_t tw_shift = SL >= 0 ? (uint32_t)STW : tw_shift_rt, log_cols = SL >= 0 ? (uint32_t)SLC : log_cols_rt;
@@ -158,19 +158,19 @@ __device__ __forceinline__ void dit_pass(Lw *sm, const Lw *tw, uint32_t L_rt, ui
         for (uint32_t j = 0; j < G; j++) sm[base ^ joff[j]] = to_lds(p2f::red(v[j]));
     }
 }
-template <bool DIF>
-__device__ __forceinline__ void run_stages(Lw *sm, const Lw *tw, uint32_t L, uint32_t first, uint32_t count, uint32_t tw_shift,
+template <bool DIF, class TW = Lw>
+__device__ __forceinline__ void run_stages(Lw *sm, const TW *tw, uint32_t L, uint32_t first, uint32_t count, uint32_t tw_shift,
                                            uint32_t log_cols, uint32_t tid, uint32_t nt) {
     uint32_t s = first, left = count;
     while (left) {
         if (left >= 3) {
-            if (DIF) dif_pass<3>(sm, tw, L, s, tw_shift, log_cols, tid, nt); else dit_pass<3>(sm, tw, L, s, tw_shift, tid, nt);
+            if constexpr (DIF) dif_pass<3, -1, 0, 0, 0, TW>(sm, tw, L, s, tw_shift, log_cols, tid, nt); else dit_pass<3>(sm, tw, L, s, tw_shift, tid, nt);
             s += 3; left -= 3;
         } else if (left == 2) {
-            if (DIF) dif_pass<2>(sm, tw, L, s, tw_shift, log_cols, tid, nt); else dit_pass<2>(sm, tw, L, s, tw_shift, tid, nt);
+            if constexpr (DIF) dif_pass<2, -1, 0, 0, 0, TW>(sm, tw, L, s, tw_shift, log_cols, tid, nt); else dit_pass<2>(sm, tw, L, s, tw_shift, tid, nt);
             s += 2; left -= 2;
         } else {
-            if (DIF) dif_pass<1>(sm, tw, L, s, tw_shift, log_cols, tid, nt); else dit_pass<1>(sm, tw, L, s, tw_shift, tid, nt);
+            if constexpr (DIF) dif_pass<1, -1, 0, 0, 0, TW>(sm, tw, L, s, tw_shift, log_cols, tid, nt); else dit_pass<1>(sm, tw, L, s, tw_shift, tid, nt);
             s += 1; left -= 1;
         }
         __syncthreads();
@@ -178,14 +178,14 @@ __device__ __forceinline__ void run_stages(Lw *sm, const Lw *tw, uint32_t L, uin
 }
 
 // the same with compile-time geometry: stages FIRST .. FIRST+COUNT-1 of a 2^L-point transform
-template <bool DIF, int L, int FIRST, int COUNT, int TWS, int LC>
-__device__ __forceinline__ void run_stages_static(Lw *sm, const Lw *tw, uint32_t tid, uint32_t nt) {
+template <bool DIF, int L, int FIRST, int COUNT, int TWS, int LC, class TW = Lw>
+__device__ __forceinline__ void run_stages_static(Lw *sm, const TW *tw, uint32_t tid, uint32_t nt) {
     if constexpr (COUNT > 0) {
         constexpr int R = COUNT >= 3 ? 3 : COUNT;
-        if constexpr (DIF) dif_pass<R, L, FIRST, TWS, LC>(sm, tw, 0, 0, 0, 0, tid, nt);
+        if constexpr (DIF) dif_pass<R, L, FIRST, TWS, LC, TW>(sm, tw, 0, 0, 0, 0, tid, nt);
         else dit_pass<R, L, FIRST, TWS>(sm, tw, 0, 0, 0, tid, nt);
         __syncthreads();
-        run_stages_static<DIF, L, FIRST + R, COUNT - R, TWS, LC>(sm, tw, tid, nt);
+        run_stages_static<DIF, L, FIRST + R, COUNT - R, TWS, LC, TW>(sm, tw, tid, nt);
     }
 }
 
@@ -198,22 +198,22 @@ __global__ void __launch_bounds__(1024) ntt_strided_kernel(const uint32_t *src, 
     const uint32_t rows = 1u << log_rows, cols = 1u << log_cols, cmask = cols - 1;
     const uint32_t tile_elems = rows << log_cols;
     Lw *sm = reinterpret_cast<Lw *>(lds);
-    Lw *tw = sm + tile_elems;  // rows/2 entries: w_rows^e (canonical)
+    double *tw = reinterpret_cast<double *>(sm + tile_elems);  // rows/2 entries: w_rows^e (canonical) as doubles: no conversion per use
     uint32_t *col = data + (size_t)blockIdx.y * col_stride;
     const uint32_t *scol = src + (size_t)blockIdx.y * col_stride;
     const uint32_t c0 = blockIdx.x << log_cols;
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
 
-    for (uint32_t e = tid; e < rows / 2; e += nt) tw[swz(e)] = (Lw)tabs.lde_tw_c[rows / 2 - 1 + e];
+    for (uint32_t e = tid; e < rows / 2; e += nt) tw[swz(e)] = (double)(Lw)tabs.lde_tw_c[rows / 2 - 1 + e];
     for (uint32_t idx = tid; idx < tile_elems; idx += nt) {
         uint32_t r = idx >> log_cols, c = idx & cmask;
         sm[swz(idx)] = (Lw)scol[(size_t)r * row_stride + c0 + c];      // a word in [0, p) is a valid residue in (-p, p)
     }
     __syncthreads();
     // forward DIF over the row index (the two tile shapes of 2^21- and 2^22-row traces with literal geometry)
-    if (log_rows == 9 && log_cols == 4) run_stages_static<true, 9, 0, 9, 0, 4>(sm, tw, tid, nt);
-    else if (log_rows == 10 && log_cols == 4) run_stages_static<true, 10, 0, 10, 0, 4>(sm, tw, tid, nt);
-    else run_stages<true>(sm, tw, log_rows, 0, log_rows, 0, log_cols, tid, nt);
+    if (log_rows == 9 && log_cols == 4) run_stages_static<true, 9, 0, 9, 0, 4, double>(sm, tw, tid, nt);
+    else if (log_rows == 10 && log_cols == 4) run_stages_static<true, 10, 0, 10, 0, 4, double>(sm, tw, tid, nt);
+    else run_stages<true, double>(sm, tw, log_rows, 0, log_rows, 0, log_cols, tid, nt);
     for (uint32_t idx = tid; idx < tile_elems; idx += nt) {
         uint32_t q = idx >> log_cols, c = idx & cmask;
         uint32_t kf = bitrev(q, log_rows);
@@ -403,7 +403,7 @@ hipError_t launch_coset_lde(hipStream_t st, const NttTables &tabs, uint32_t *d_i
     // (at least 16 consecutive words = 64-B segments, so 64 KiB tiles at n = 22)
     uint32_t b = 13 - log_n1 < 4 ? 4 : 13 - log_n1;
     if (log_n1) {
-        size_t lds = ((size_t)(1u << (log_n1 + b)) + (1u << (log_n1 - 1))) * 4;
+        size_t lds = ((size_t)(1u << (log_n1 + b)) + (1u << log_n1)) * 4;   // tile words + rows / 2 twiddles as doubles
         if (lds > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_strided_kernel<true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -421,7 +421,7 @@ hipError_t launch_coset_lde(hipStream_t st, const NttTables &tabs, uint32_t *d_i
         lde_block_kernel<<<grid, T_BLOCK, lds, st>>>(log_n1 ? d_scratch : d_in, d_out, log_n, log_n1, shift_mode, tabs);
     }
     if (log_n1) {
-        size_t lds = ((size_t)(1u << (log_n1 + b)) + (1u << (log_n1 - 1))) * 4;
+        size_t lds = ((size_t)(1u << (log_n1 + b)) + (1u << log_n1)) * 4;   // tile words + rows / 2 twiddles as doubles
         dim3 grid((2u << log_n2) >> b, width);
         ntt_strided_kernel<false><<<grid, T_STRIDED, lds, st>>>(d_out, d_out, 2 * n, log_n1, 2u << log_n2, b, log_n + 1, tabs);
     }
