@@ -3,6 +3,7 @@
 // computes returns DVT_ERR_DEVICE.  (dvt_machine_verify is host-only by nature.)
 #include "../../include/dvt_prover.h"
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdarg>
@@ -571,7 +572,8 @@ struct Pipeline {
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::pair<size_t, rv32::Snapshot>> snaps;
-    bool snaps_closed = false, abort = false, fast_done = false;
+    bool snaps_closed = false, fast_done = false;
+    std::atomic<bool> abort{false};   // (also read outside the mutex by a worker that is about to build auxiliary traces)
     std::vector<rv32::CycleRec *> free_bufs;
     std::map<size_t, ReadyShard> ready;
     // results of the fast pass
@@ -747,9 +749,10 @@ static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_buf
             }
             if (!got) { have_prev = false; break; }
             if (rc == DVT_OK) {
-                HIP_TRY(p, hipStreamWaitEvent(p->eng.stream, ev, 0));
-                // (the event is re-recorded per shard: wait for this copy before the buffer can be reused / the event re-armed)
-                if (hipEventSynchronize(ev) != hipSuccess) rc = fail(p, DVT_ERR_DEVICE, "record upload failed");
+                // (no early return in this scope: the executor threads are joined and the job released below on every path)
+                // the event is re-recorded per shard: wait for this copy before the buffer can be reused / the event re-armed
+                if (hipStreamWaitEvent(p->eng.stream, ev, 0) != hipSuccess || hipEventSynchronize(ev) != hipSuccess)
+                    rc = fail(p, DVT_ERR_DEVICE, "record upload failed");
             }
             have_prev = true;
             prev_buf = r.buf;
@@ -1038,10 +1041,16 @@ int dvt_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, size_t pr
         const uint32_t nshards = r.len(1 << 16);
         if (nshards == 0) return reject(DVT_ERR_REJECTED, "no shards");
         const uint32_t ec = r.u32(), pvl = r.len(1 << 24);
+        // the AIR pins exit codes below 2^24 (the code itself, not a residue): a container word ec + p would pass the
+        // comparison mod p below and be reported to the caller as is
+        if (ec >> 24) return reject(DVT_ERR_REJECTED, "exit code out of range");
         std::vector<uint8_t> pv(pvl);
         for (uint32_t i = 0; i < pvl; i += 4) {
             uint32_t v = r.u32();
-            for (uint32_t k = 0; k < 4 && i + k < pvl; k++) pv[i + k] = (uint8_t)(v >> (8 * k));
+            for (uint32_t k = 0; k < 4; k++) {
+                if (i + k < pvl) pv[i + k] = (uint8_t)(v >> (8 * k));
+                else if ((v >> (8 * k)) & 0xff) return reject(DVT_ERR_REJECTED, "non-zero padding after the public values");   // (one encoding per proof)
+            }
         }
         std::vector<ShardProof> sps(nshards);
         for (uint32_t i = 0; i < nshards; i++) {
@@ -1065,8 +1074,9 @@ int dvt_verify(const uint8_t *vk, size_t vk_len, const uint8_t *proof, size_t pr
             if (pubv[4] != (last ? 1u : 0u)) return reject(DVT_ERR_REJECTED, "is_last flag does not match the shard's position");
             if (i == 0 && pubv[0] != key.extra[0] % P) return reject(DVT_ERR_REJECTED, "first shard does not start at the entry point");
             if (i > 0 && pubv[0] != sps[i - 1].public_values[1].canonical()) return reject(DVT_ERR_REJECTED, "shards do not chain (pc)");
-            if (last && pubv[1] != 0) return reject(DVT_ERR_REJECTED, "execution did not halt");
-            if (!last && pubv[1] == 0) return reject(DVT_ERR_REJECTED, "halt before the last shard");
+            // only a HALT row has next_pc = HALT_PC (tools/airgen/rv32.py): control flow that merely reaches address 0 does not count
+            if (last && pubv[1] != rv32::HALT_PC) return reject(DVT_ERR_REJECTED, "execution did not halt");
+            if (!last && pubv[1] == rv32::HALT_PC) return reject(DVT_ERR_REJECTED, "halt before the last shard");
             if (last && pubv[2] != ec % P) return reject(DVT_ERR_REJECTED, "exit code mismatch");
             // chip set: program, byte, cpu, mem_image always; mem_init in the last shard only; shift / muldiv when the shard uses them
             bool have[rv32::N_CHIPS] = {};

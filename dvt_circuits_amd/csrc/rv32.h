@@ -43,6 +43,9 @@ constexpr uint32_t SYS_COMMIT = 0x10;
 constexpr uint32_t SYS_SHA_EXTEND = 0x00300105u;  // SP1 syscall code (byte 1 = 1: the call has a precompile table)
 constexpr uint32_t SYS_SHA_COMPRESS = 0x00010106u;
 constexpr uint32_t REG_A1 = 11;
+constexpr uint32_t REG_BASE = ADDR_LIMIT;     // the registers are words REG_BASE + 0..31 of the memory argument: above every guest address
+constexpr uint32_t HALT_PC = 1u << 30;        // next_pc of a HALT row (tools/airgen/rv32.py): no other row can produce it
+constexpr uint32_t BAD_PC = 1;                // program-table target of a JAL / branch whose static target lies outside the text
 constexpr uint32_t MAX_SHARDS = 65535;        // shard numbers travel as 16-bit halves of the cycle records
 constexpr uint32_t ALU_SLL = 1, ALU_SRL = 2, ALU_SRA = 3;  // alu-bus opcodes (chips outside the cpu chip): shift chip
 constexpr uint32_t ALU_MULH = 4, ALU_MULHSU = 5, ALU_DIV = 6, ALU_DIVU = 7, ALU_REM = 8, ALU_REMU = 9;  // muldiv chip
@@ -66,6 +69,7 @@ struct Instr {
     uint8_t supported;  // has a chip (otherwise executes only)
     uint8_t kind;       // Kind
     uint32_t tgt_idx;   // branches / JAL: index of the target in Program::instrs (the sentinel's when it lies outside the text)
+    uint32_t tgt_raw;   // branches / JAL: the target as decoded (tgt is BAD_PC when it lies outside the text)
 };
 
 struct Program {
@@ -435,8 +439,8 @@ DVT_HD void fill_cpu_row(const CycleRec &r, const Instr &in, uint32_t row, uint3
         if (is_commit || is_pre) {
             const uint32_t u_clk = is_pre ? clk : 0u, u_sh = is_pre ? shard : 0u;
             s.put(U + 3, u_clk); s.put(U + 21, u_sh);
-            // the port's address expression u0 + 256 u1 + 65536 u2 + 2^24 u3 - (u21 + 2 u22 + 3 u23) must be 11
-            const Fp u0 = Fp::from_canonical(REG_A1) - Fp::from_canonical(256u * is_pre) - Fp::from_canonical(65536) * Fp::from_canonical(pre_inv) -
+            // the port's address expression u0 + 256 u1 + 65536 u2 + 2^24 u3 - (u21 + 2 u22 + 3 u23) must be REG_BASE + 11
+            const Fp u0 = Fp::from_canonical(REG_BASE + REG_A1) - Fp::from_canonical(256u * is_pre) - Fp::from_canonical(65536) * Fp::from_canonical(pre_inv) -
                           Fp::from_canonical(1u << 24) * Fp::from_canonical(u_clk) + Fp::from_canonical(u_sh);
             s.put(U + 0, u0.canonical());
             mem_port(r.m_prev);

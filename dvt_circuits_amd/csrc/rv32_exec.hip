@@ -153,7 +153,7 @@ bool load_elf(const uint8_t *elf, size_t n, Program *out, std::string *err) {
     if (phentsize < 32 || (uint64_t)phoff + (uint64_t)phentsize * phnum > n) return bad("bad program headers");
     std::map<uint32_t, uint32_t> image;
     bool have_text = false;
-    for (uint32_t r = 0; r < 32; r++) image[r] = 0;  // registers live at word addresses 0..31, initial value 0
+    for (uint32_t r = 0; r < 32; r++) image[REG_BASE + r] = 0;  // registers: words REG_BASE + 0..31 of the memory argument, initial value 0
     for (uint32_t i = 0; i < phnum; i++) {
         const uint8_t *ph = elf + phoff + (size_t)i * phentsize;
         if (rd32(ph) != 1) continue;  // PT_LOAD
@@ -181,6 +181,11 @@ bool load_elf(const uint8_t *elf, size_t n, Program *out, std::string *err) {
                 Instr &in = p.instrs[k];
                 const uint32_t t = in.tgt - vaddr;
                 in.tgt_idx = (in.tgt >= vaddr && t % 4 == 0 && t / 4 < words) ? t / 4 : words;
+                in.tgt_raw = in.tgt;
+                // a static target outside the text traps in the executor; in the program table it becomes a value that is
+                // no row's pc and not HALT_PC (a raw 32-bit target could alias a valid one mod p)
+                const bool cf = in.flags & (FL(F_JAL) | FL(F_BEQ) | FL(F_BNE) | FL(F_BLT) | FL(F_BGE) | FL(F_BLTU) | FL(F_BGEU));
+                if (cf && in.tgt_idx == words) in.tgt = BAD_PC;
             }
         }
     }
@@ -198,7 +203,7 @@ Vm::Vm(const Program &p, const std::vector<std::vector<uint8_t>> *in, uint32_t l
     : prog(p), pc(p.entry), log_shard(ls), stdin_bufs(in), holders(N_PAGES), raw(N_PAGES, nullptr), own(N_PAGES, 0) {
     for (auto &c : regs) c = Cell{0, FL_IMG, 0};
     for (auto &kv : prog.image)
-        if (kv.first >= 32) { Cell &c = at(kv.first); c.val = kv.second; c.flags = FL_IMG; }
+        if (kv.first < REG_BASE) { Cell &c = at(kv.first); c.val = kv.second; c.flags = FL_IMG; }
 }
 
 Vm::Vm(const Program &p, const std::vector<std::vector<uint8_t>> *in, uint32_t ls, const Snapshot &s)
@@ -254,7 +259,7 @@ void Vm::run_shard(bool trace, ShardOut *out, uint64_t max_total_cycles) {
         out->sha_ext.clear();
         out->sha_cmp.clear();
         run<true>(out, budget);
-        out->next_pc = pc;   // 0 after HALT
+        out->next_pc = pc;   // HALT_PC after HALT
     } else {
         run<false>(nullptr, budget);
     }
@@ -505,7 +510,7 @@ L_ECALL: {
     if (halted) {
         if (TRACE) { rec.a = a; rec.b = b; rec.c = c; rec.sh_ab = sha | (shb << 16); rec.sh_cm = shc | (shm << 16); recs[done] = rec; }
         done++;
-        pc = 0;
+        pc = HALT_PC;
         goto finished;
     }
     NEXT();
@@ -523,7 +528,7 @@ L_UNSUP: {
 L_OOB:
     // control left the text: report the address it went to (a JALR recorded it; a static jump's target is in `prev`)
     if (jump_pc) pc = jump_pc;
-    else if (prev && prev->tgt_idx == ninstr && (prev->kind == K_JAL || (prev->kind >= K_BEQ && prev->kind <= K_BGEU && prev + 1 != ip))) pc = prev->tgt;
+    else if (prev && prev->tgt_idx == ninstr && (prev->kind == K_JAL || (prev->kind >= K_BEQ && prev->kind <= K_BGEU && prev + 1 != ip))) pc = prev->tgt_raw;
     else pc = ip->pc;
     trap("pc outside text");
     goto finished;
@@ -555,7 +560,7 @@ std::vector<MemInitRow> Vm::mem_rows() const {
     rows.reserve(prog.image.size() + first_touch.size());
     for (auto &kv : prog.image) {
         MemInitRow r{kv.first, kv.second, kv.second, 0, 0, 1};
-        const Cell *c = kv.first < 32 ? &regs[kv.first] : peek(kv.first);
+        const Cell *c = kv.first >= REG_BASE ? &regs[kv.first - REG_BASE] : peek(kv.first);
         if (c && c->tsh) { r.f = c->val; r.fts = c->ts(); r.fsh = c->sh(); }
         rows.push_back(r);
     }
@@ -711,8 +716,9 @@ bool build_aux_host(const ShardMeta &S, const std::vector<AluEvent> &alu, const 
             for (uint32_t w : {m.addr, d}) {
                 sink.byte(B_RANGE - 1, ((w & 0xff) << 8) | ((w >> 8) & 0xff));
                 sink.byte(B_RANGE - 1, (((w >> 16) & 0xff) << 8) | (w >> 24));
-                sink.byte(B_LTU - 1, ((w >> 24) << 8) | (ADDR_LIMIT >> 24));
             }
+            sink.byte(B_LTU - 1, ((m.addr >> 24) << 8) | ((ADDR_LIMIT >> 24) + 1));   // (+ 1: the registers sit at REG_BASE)
+            sink.byte(B_LTU - 1, ((d >> 24) << 8) | (ADDR_LIMIT >> 24));
             if (!m.is_img) {
                 sink.byte(B_RANGE - 1, ((m.v & 0xff) << 8) | ((m.v >> 8) & 0xff));
                 sink.byte(B_RANGE - 1, (((m.v >> 16) & 0xff) << 8) | (m.v >> 24));

@@ -101,6 +101,26 @@ struct ConstraintFolder {
         return d;
     }
 
+    // ---- polynomial identities (tools/airgen/dsl.py assert_poly_zero): the coefficient constraints first .. first + K - 1
+    // of one big-integer identity are folded in closed form, alpha^first (C(alpha) + (alpha - 256) W(alpha)).
+    // V(alpha) = sum_i alpha^i v_i of a limb vector:
+    DVT_HD Fp4 poly(const T *v, int n) const {
+        if constexpr (BASE) {
+            DotAcc4 s;
+            for (int k = 0; k < n; k++) {
+                s.add(alpha_d + 4 * k, v[k]);
+                if ((k & 31) == 31) s.reduce();
+            }
+            return s.value();
+        } else {
+            Fp4 a = Fp4::zero();
+            for (int k = 0; k < n; k++) a += alpha_pows[k] * v[k];
+            return a;
+        }
+    }
+    DVT_HD Fp4 alpha_minus(uint32_t k) const { return alpha_pows[1] - Fp::from_canonical(k); }
+    DVT_HD void fold_poly(int first, const Fp4 &v) { acc += alpha_pows[first] * v; }
+
     DVT_HD void constraint(int idx, int when, const T &v) {
         if (when == WHEN_ALL) fold_t(idx, v);
         else if (when == WHEN_FIRST) fold_t(idx, v * sel_first);

@@ -19,6 +19,9 @@ import numpy as np
 P = 2013265921
 M32 = 0xFFFFFFFF
 ADDR_LIMIT = 0x38000000
+REG_BASE = ADDR_LIMIT        # the registers are words REG_BASE + 0..31 of the memory argument (above every guest address)
+HALT_PC = 1 << 30            # next_pc of a HALT row: no other row can produce it
+BAD_PC = 1                   # program-table target of a JAL / branch whose static target lies outside the text
 B_AND, B_OR, B_XOR, B_LTU, B_MSB, B_RANGE, B_U16, B_ADDR = 1, 2, 3, 4, 5, 6, 7, 8
 SHA_K = [
     0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
@@ -40,11 +43,11 @@ def inv(x):
 
 # ---------------------------------------------------------------------------------------------- decoding
 class Ins:
-    __slots__ = ("pc", "word", "kind", "rd", "rs1", "rs2", "imm", "off", "tgt", "alu", "imm_form", "ok")
+    __slots__ = ("pc", "word", "kind", "rd", "rs1", "rs2", "imm", "off", "tgt", "tgt_col", "alu", "imm_form", "ok")
 
     def __init__(self, pc, word):
         self.pc, self.word, self.kind, self.rd, self.rs1, self.rs2 = pc, word, None, 0, 0, 0
-        self.imm = self.off = self.tgt = self.alu = 0
+        self.imm = self.off = self.tgt = self.tgt_col = self.alu = 0
         self.imm_form, self.ok = False, True
 
 
@@ -184,6 +187,11 @@ class Run:
                 self.n_instr = (filesz + 3) // 4
                 for j in range(self.n_instr):
                     self.text[vaddr + 4 * j] = decode(self.image_mem[vaddr + 4 * j], vaddr + 4 * j)
+        # the target COLUMN of a JAL / branch: the target itself when it is an instruction of the text, BAD_PC otherwise
+        # (the machine traps there; a raw 32-bit value could alias a valid pc mod p)
+        for i in self.text.values():
+            if i.kind in ("jal", "beq", "bne", "blt", "bge", "bltu", "bgeu"):
+                i.tgt_col = i.tgt if i.tgt in self.text else BAD_PC
         # the program table lists the instructions that have a chip, in address order
         self.provable = [i for _, i in sorted(self.text.items()) if i.ok]
 
@@ -308,7 +316,7 @@ class Run:
                 if b == 0x00:
                     if c >> 24:
                         raise Trap("HALT with an exit code of 2^24 or more at pc 0x%x" % pc)
-                    self.halted, self.exit_code, nxt = True, sx(c), 0
+                    self.halted, self.exit_code, nxt = True, sx(c), HALT_PC
                 elif b == 0x02:
                     if a1 + a2 > ADDR_LIMIT:
                         raise Trap("WRITE buffer out of range at pc 0x%x" % pc)
@@ -408,16 +416,16 @@ class Run:
             cur["rows"].append(row)
             pc, i_in, self.cycles = nxt, i_in + 1, self.cycles + 1
             if self.halted:
-                cur["next_pc"] = 0
+                cur["next_pc"] = HALT_PC
                 self.shards.append(cur)
                 return
 
     # ---- the sorted initial / final table of the last shard
     def mem_rows(self):
         rows = []
-        for addr in range(32):
-            t = self.reg_t[addr]
-            rows.append((addr, 0, self.reg[addr] if t != (0, 0) else 0, t, 1))
+        for r in range(32):
+            t = self.reg_t[r]
+            rows.append((REG_BASE + r, 0, self.reg[r] if t != (0, 0) else 0, t, 1))
         for addr, v in self.image_mem.items():
             t = self.mem_t.get(addr, (0, 0))
             rows.append((addr, v, self.mem[addr] if t != (0, 0) else v, t, 1))
@@ -504,7 +512,7 @@ def traces(run: Run, pos: int):
         put("clk", clk); put("pc", ins.pc); put("next_pc", row.next_pc)
         put("rd", ins.rd); put("rs1", ins.rs1); put("rs2", ins.rs2)
         putv("imm", byts(ins.imm | ins.off))          # one immediate field: operand / constant or address offset, never both
-        put("aux", ins.tgt + (ALU_CODES[ins.alu] if k == "alu" else 0))
+        put("aux", ins.tgt_col + (ALU_CODES[ins.alu] if k == "alu" else 0))
         put("bit_op", bit_op_of.get(k, 0)); put("cmp_signed", int(k in signed_forms))
         putv("a", byts(a)); putv("b", byts(b)); putv("c", byts(c))
         put(fam_of[k], 1)
@@ -611,8 +619,8 @@ def traces(run: Run, pos: int):
             put("sys_m", int(is_commit or is_pre))
             if is_commit or is_pre:
                 U[3], U[21] = (clk, shard) if is_pre else (0, 0)
-                # the port's address expression u0 + 256 u1 + 65536 u2 + 2^24 u3 - (u21 + 2 u22 + 3 u23) is 11
-                U[0] = (11 - 256 * U[1] - 65536 * U[2] - (1 << 24) * U[3] + U[21]) % P
+                # the port's address expression u0 + 256 u1 + 65536 u2 + 2^24 u3 - (u21 + 2 u22 + 3 u23) is register a1's word
+                U[0] = (REG_BASE + 11 - 256 * U[1] - 65536 * U[2] - (1 << 24) * U[3] + U[21]) % P
                 mem_port(row.m_prev, row.m_val, row.mem)
         putv("u", U)
         put("pb_hi", hi["pb"]); put("pc_hi", hi["pc"]); put("pa_hi", hi["pa"])
@@ -749,8 +757,8 @@ def traces(run: Run, pos: int):
             d = addr - prev - 1 if prev is not None else 0
             putv("ab", byts(addr)); putv("v", byts(v)); putv("f", byts(f)); putv("d", byts(d))
             put("fts", t[1]); put("fsh", t[0]); put("is_img", is_img); put("is_real", 1)
-            for w in (addr, d):
-                lk.add(B_RANGE, byts(w)[0], byts(w)[1]); lk.add(B_RANGE, byts(w)[2], byts(w)[3]); lk.add(B_LTU, byts(w)[3], ADDR_LIMIT >> 24)
+            for w, top in ((addr, (ADDR_LIMIT >> 24) + 1), (d, ADDR_LIMIT >> 24)):      # (+ 1: the registers at REG_BASE)
+                lk.add(B_RANGE, byts(w)[0], byts(w)[1]); lk.add(B_RANGE, byts(w)[2], byts(w)[3]); lk.add(B_LTU, byts(w)[3], top)
             if not is_img:
                 lk.add(B_RANGE, byts(v)[0], byts(v)[1]); lk.add(B_RANGE, byts(v)[2], byts(v)[3])
             prev = addr
@@ -861,7 +869,7 @@ def traces(run: Run, pos: int):
     for r in range(np_rows):
         ins = run.provable[r] if r < len(run.provable) else run.provable[0]
         k = ins.kind
-        vals = dict(pc=ins.pc, rd=ins.rd, rs1=ins.rs1, rs2=ins.rs2, aux=ins.tgt + (ALU_CODES[ins.alu] if k == "alu" else 0))
+        vals = dict(pc=ins.pc, rd=ins.rd, rs1=ins.rs1, rs2=ins.rs2, aux=ins.tgt_col + (ALU_CODES[ins.alu] if k == "alu" else 0))
         for i in range(4):
             vals[f"imm[{i}]"] = byts(ins.imm | ins.off)[i]
         vals["bit_op"], vals["cmp_signed"] = bit_op_of.get(k, 0), int(k in signed_forms)
@@ -885,7 +893,7 @@ def traces(run: Run, pos: int):
         bprep[chipb.prep_names.index(nm)] = v
     out["byte"] = (lk.byte, bprep)
     cidi, chipi = chips["mem_image"]
-    img = sorted([(a_, 0) for a_ in range(32)] + list(run.image_mem.items()))
+    img = sorted([(REG_BASE + r_, 0) for r_ in range(32)] + list(run.image_mem.items()))
     ni = 1 << log2ceil(len(img))
     iprep = np.zeros((chipi.prep_width, ni), np.int64)
     for r, (addr, v) in enumerate(img):

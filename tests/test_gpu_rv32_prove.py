@@ -210,6 +210,14 @@ def test_verify_rejects_hostile_containers(gpu):
     for q, pw in ((0, POW), (Q, 31), (Q, 40), (5000, POW)):
         ok, _, _, why = capi.verify(vk, proof, q, pw)
         assert not ok
+    # the container's exit-code word is compared mod p with the proven public value; ec + p must not be
+    # accepted (and then reported to the caller as the exit code)
+    assert w[2] == 0
+    for evil in (2013265921, 1 << 24, 0xF0000002):
+        t = w.copy()
+        t[2] = evil
+        ok, _, _, why = capi.verify(vk, t.tobytes(), Q, POW)
+        assert not ok and "exit code" in why, why
     gpu.pk_free(pk)
 
 

@@ -53,7 +53,7 @@ def test_arith_guest_executes_and_traces_satisfy_air(air):
     assert rep["halted"] and rep["exit_code"] == 0 and not rep["unprovable"]
     assert out == want and pv == guests.checksum(want)
     chips, pubs = check_traces(air, elf)
-    assert pubs[1] == 0 and pubs[2] == 0  # halted, exit code 0
+    assert pubs[1] == 1 << 30 and pubs[2] == 0  # halted (next_pc = HALT_PC), exit code 0
 
 
 def test_bignum_guest(air):

@@ -126,6 +126,11 @@ class Interaction:
             assert v.deg <= 1, "interaction values must be affine"
 
 
+class PolyRel:
+    """A big-integer identity checked limb by limb (see Chip.assert_poly_zero)."""
+    __slots__ = ("name", "terms", "w", "w_off", "sel", "first", "K", "coef_expr")
+
+
 class Chip:
     def __init__(self, name):
         self.name = name
@@ -133,6 +138,8 @@ class Chip:
         self.constraints = []  # (expr, when) when in {"all","first","last","trans"}
         self.interactions = []
         self.n_pub = 0
+        self.poly_rels = []    # PolyRel groups: seal() appends their coefficient constraints as the LAST entries of self.constraints
+        self._sealed = False
 
     # ---- columns
     def col(self, name):
@@ -158,6 +165,7 @@ class Chip:
 
     # ---- constraints (degree counted with the selector: first/last/trans add 1)
     def assert_zero(self, e, when="all"):
+        assert not self._sealed
         e = Expr.wrap(e)
         if e.is_const():
             assert e.args[0] == 0, f"{self.name}: constant non-zero constraint"
@@ -171,6 +179,86 @@ class Chip:
 
     def assert_bool(self, x):
         self.assert_zero(x * (x - 1))
+
+    # ---- big-integer identities over byte limbs
+    def assert_poly_zero(self, name, terms, sel, cases):
+        """sum_terms coef * s * A(t) * B(t) = 0 at t = 256, as an identity of INTEGERS, where every term is
+        (coef, s, A, B): coef an integer, s a column (a 0/1 selector) or None, A and B limb vectors (lists of columns,
+        or lists of integers = constants; B may be None).  Column limbs are range-checked bytes (the caller's duty).
+        With C(t) the polynomial of the left-hand side, the witness W (K - 1 carries) satisfies C(t) = (256 - t) W(t), i.e.
+            c_k + W_(k-1) - 256 W_k = 0      for k = 0 .. K - 1   (W_(-1) = W_(K-1) = 0),
+        one degree <= 3 constraint per coefficient; W_k = w_k - sel * off_k with w_k a new column that the caller
+        range-checks to 16 bits (returned).  |c_k| < 2^25 and |256 W_k| < 2^25 keep every equation far below p, so it
+        holds over the integers, and so does the identity at t = 256.
+        `sel` is the chip's "row is real" selector (the offsets vanish on padding rows); every term must carry a
+        selector that is 0 on padding rows.  `cases` lists the selector assignments that can occur ({column: 0/1} dicts,
+        e.g. one per operation of the chip): the carry offsets off_k are sized from the extreme values of c_k over them.
+        The constraints are appended as ordinary ones (the oracle evaluates them as written); the product's generated
+        code evaluates a whole group at the folding challenge instead: sum_k alpha^(s+k) (...) =
+        alpha^s (C(alpha) + (alpha - 256) W(alpha)), O(limbs) instead of O(limbs^2) multiplications (emit.py)."""
+        def vlen(v):
+            return len(v)
+
+        K = max((vlen(a) + (vlen(b) - 1 if b is not None else 0)) for _, _, a, b in terms)
+        # ---- coefficient expressions and their ranges per case
+        coef_expr = [Expr.const(0) for _ in range(K)]
+        lo = [[0] * K for _ in cases]
+        hi = [[0] * K for _ in cases]
+        for coef, s, a, b in terms:
+            assert s is not None, "every term needs a selector that vanishes on padding rows"
+            bb = b if b is not None else [1]
+            for i, ai in enumerate(a):
+                for j, bj in enumerate(bb):
+                    ca, cb = isinstance(ai, int), isinstance(bj, int)
+                    if (ca and ai == 0) or (cb and bj == 0):
+                        continue
+                    e = Expr.wrap(coef) * s * Expr.wrap(ai) * Expr.wrap(bj)
+                    coef_expr[i + j] = coef_expr[i + j] + e
+                    mx = coef * (ai if ca else 255) * (bj if cb else 255)
+                    mn = 0 if not (ca and cb) else mx
+                    for ci, case in enumerate(cases):
+                        if case.get(s.id, 0):
+                            lo[ci][i + j] += min(mn, mx)
+                            hi[ci][i + j] += max(mn, mx)
+        # ---- carry ranges: W_k = (c_k + W_(k-1)) / 256
+        wlo, whi = [0] * K, [0] * K
+        for ci in range(len(cases)):
+            l = h = 0
+            for k in range(K):
+                l, h = (lo[ci][k] + l) // 256, -((-(hi[ci][k] + h)) // 256)
+                wlo[k], whi[k] = min(wlo[k], l), max(whi[k], h)
+        assert not self._sealed
+        rel = PolyRel()
+        rel.name, rel.terms, rel.sel, rel.K = name, terms, sel, K
+        width = max(whi[k] - wlo[k] for k in range(K - 1))
+        assert width < 1 << 17, f"{self.name}.{name}: carries span {width} values"
+        for k in range(K):
+            assert max(abs(lo_[k]) for lo_ in lo) < 1 << 25 and max(abs(hi_[k]) for hi_ in hi) < 1 << 25
+        lo16 = [self.col(f"{name}_w[{k}]") for k in range(K - 1)]
+        # carries wider than 16 bits (three or more limb products on a side): one more bit per carry
+        top = [self.col(f"{name}_wb[{k}]") for k in range(K - 1)] if width >= 1 << 16 else None
+        for t in top or []:
+            self.assert_zero(t * (t - 1))
+        rel.w = [lo16[k] + 65536 * top[k] for k in range(K - 1)] if top else lo16
+        rel.w_off = [-wlo[k] for k in range(K - 1)]
+        rel.coef_expr = coef_expr
+        rel.first = None
+        self.poly_rels.append(rel)
+        return lo16
+
+    def seal(self):
+        """append the coefficient constraints of the polynomial identities (after every other constraint)"""
+        if self._sealed:
+            return
+        self._sealed = True
+        for rel in self.poly_rels:
+            rel.first = len(self.constraints)
+            for k in range(rel.K):
+                W_prev = rel.w[k - 1] - rel.sel * rel.w_off[k - 1] if k else Expr.const(0)
+                W_k = rel.w[k] - rel.sel * rel.w_off[k] if k < rel.K - 1 else Expr.const(0)
+                e = rel.coef_expr[k] + W_prev - 256 * W_k
+                assert e.deg <= 3
+                self.constraints.append((e, "all"))
 
     # ---- LogUp
     def send(self, bus, vals, mult=1, scope="local"):
@@ -192,5 +280,6 @@ class Machine:
     def __init__(self, name, chips, buses):
         self.name, self.chips, self.buses = name, chips, buses
         for c in chips:
+            c.seal()
             for it in c.interactions:
                 assert it.bus in buses, f"{c.name}: unknown bus {it.bus}"

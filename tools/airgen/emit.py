@@ -14,6 +14,19 @@ WHEN_ID = {"all": 0, "first": 1, "last": 2, "trans": 3}
 SCOPE_ID = {"local": 0, "global": 1}
 
 
+class Names:
+    """v<n> names in order of first use: the generated text must not depend on Expr.id, a process-global counter"""
+
+    def __init__(self):
+        self.m = {}
+
+    def __call__(self, e):
+        n = self.m.get(e.id)
+        if n is None:
+            n = self.m[e.id] = f"v{len(self.m)}"
+        return n
+
+
 def topo(roots):
     order, seen = [], set()
     stack = [(r, False) for r in reversed(roots)]
@@ -33,10 +46,23 @@ def topo(roots):
     return order
 
 
+def n_plain(ch):
+    """constraints that are not coefficient constraints of a polynomial identity (those come last)"""
+    rels = getattr(ch, "poly_rels", [])
+    if not rels:
+        return len(ch.constraints)
+    at = rels[0].first
+    for r in rels:
+        assert r.first == at, f"{ch.name}: polynomial identities must be asserted after every other constraint"
+        at += r.K
+    assert at == len(ch.constraints), f"{ch.name}: polynomial identities must be asserted after every other constraint"
+    return rels[0].first
+
+
 def split_parts(ch):
-    """contiguous groups of the chip's constraints with roughly equal numbers of expression nodes"""
+    """contiguous groups of the chip's (plain) constraints with roughly equal numbers of expression nodes"""
     n = max(1, getattr(ch, "quotient_parts", 1))
-    total = len(ch.constraints)
+    total = n_plain(ch)
     if n == 1 or total < 2 * n:
         return [(0, total)]
     cost = [len(topo([e])) for e, _ in ch.constraints]
@@ -64,8 +90,8 @@ def cname(ch):
 
 
 # ------------------------------------------------------------------ C++ (product)
-def cpp_node(e):
-    n = f"v{e.id}"
+def cpp_node(e, nm):
+    n = nm(e)
     if e.op == "const":
         return f"const T {n} = C::K(0x{e.args[0] * R % P:08x}u);"
     if e.op == "var":
@@ -73,7 +99,7 @@ def cpp_node(e):
         if kind == "pub":
             return f"const T {n} = c.pub({idx});"
         return f"const T {n} = c.{kind}({idx}, {rot});"
-    a = [f"v{x.id}" for x in e.args]
+    a = [nm(x) for x in e.args]
     if e.op == "add":
         return f"const T {n} = {a[0]} + {a[1]};"
     if e.op == "sub":
@@ -83,6 +109,45 @@ def cpp_node(e):
     if e.op == "neg":
         return f"const T {n} = -{a[0]};"
     raise ValueError(e.op)
+
+
+def cpp_poly_group(out, rel, nm, ind):
+    """The coefficient constraints [first, first + K) of one polynomial identity, folded at once:
+    sum_k alpha^(first + k) (c_k + W_(k-1) - 256 W_k) = alpha^first (C(alpha) + (alpha - 256) W(alpha)), with
+    C(alpha) = sum_terms coef s A(alpha) B(alpha) and V(alpha) = sum_i alpha^i v_i for a limb vector V."""
+    seen = set()
+
+    def need(e):
+        for x in topo([e]):
+            if x.id not in seen:
+                seen.add(x.id)
+                out.append(ind + cpp_node(x, nm))
+        return nm(e)
+
+    vec_name = {}
+
+    def vec(v):
+        key = tuple(x if isinstance(x, int) else ("e", x.id) for x in v)
+        if key not in vec_name:
+            items = ", ".join(f"C::K(0x{x * R % P:08x}u)" if isinstance(x, int) else need(x) for x in v)
+            n = f"pv{len(vec_name)}"
+            out.append(f"{ind}const T l{n}[] = {{{items}}};")
+            out.append(f"{ind}const Fp4 {n} = c.poly(l{n}, {len(v)});")
+            vec_name[key] = n
+        return vec_name[key]
+
+    out.append(f"{ind}// polynomial identity '{rel.name}': constraints {rel.first} .. {rel.first + rel.K - 1}")
+    out.append(f"{ind}Fp4 tot = Fp4::zero();")
+    for coef, sexpr, a, b in rel.terms:
+        sc = need(Expr.wrap(coef) * sexpr)
+        va = vec(a)
+        if b is None:
+            out.append(f"{ind}tot += {va} * {sc};")
+        else:
+            out.append(f"{ind}tot += ({va} * {vec(b)}) * {sc};")
+    wl = [w - rel.sel * off for w, off in zip(rel.w, rel.w_off)]
+    out.append(f"{ind}tot += c.alpha_minus(256) * {vec(wl)};")
+    out.append(f"{ind}c.fold_poly({rel.first}, tot);")
 
 
 def emit_cpp(machine):
@@ -96,23 +161,32 @@ def emit_cpp(machine):
         out.append(f"    static constexpr int N_CONSTRAINTS = {len(ch.constraints)}, N_INTERACTIONS = {len(ch.interactions)}, MAX_ARITY = {max_ar};")
         out.append(f'    static constexpr const char *NAME = "{ch.name}";')
         # constraints, in N_PARTS contiguous groups: the gfx950 quotient runs one kernel per group (a single kernel
-        # over all of a wide chip's constraints keeps several hundred values live: 256 VGPRs + spills, one wave per SIMD)
+        # over all of a wide chip's constraints keeps several hundred values live: 256 VGPRs + spills, one wave per SIMD);
+        # every polynomial identity (dsl.Chip.assert_poly_zero) is a part of its own, folded in closed form
         parts = split_parts(ch)
-        out.append(f"    static constexpr int N_PARTS = {len(parts)};")
+        rels = getattr(ch, "poly_rels", [])
+        if n_plain(ch) == 0 and rels:
+            parts = []
+        out.append(f"    static constexpr int N_PARTS = {len(parts) + len(rels)};")
         out.append("    template <class C> DVT_HD static void constraints(C &c) {")
-        for k in range(len(parts)):
+        for k in range(len(parts) + len(rels)):
             out.append(f"        constraints_part<{k}>(c);")
         out.append("    }")
         out.append("    template <int PART, class C> DVT_HD static void constraints_part(C &c) {")
         out.append("        using T = typename C::T; (void)sizeof(T); (void)c;")
         for k, (lo, hi) in enumerate(parts):
+            names = Names()
             out.append(f"        if constexpr (PART == {k}) {{")
             roots = [e for e, _ in ch.constraints[lo:hi]]
             for e in topo(roots):
-                out.append("            " + cpp_node(e))
+                out.append("            " + cpp_node(e, names))
             for i in range(lo, hi):
                 e, when = ch.constraints[i]
-                out.append(f"            c.constraint({i}, {WHEN_ID[when]}, v{e.id});")
+                out.append(f"            c.constraint({i}, {WHEN_ID[when]}, {names(e)});")
+            out.append("        }")
+        for k, rel in enumerate(rels):
+            out.append(f"        if constexpr (PART == {len(parts) + k}) {{")
+            cpp_poly_group(out, rel, Names(), "            ")
             out.append("        }")
         out.append("    }")
         # interactions (K4 walks all of them in one kernel); for the quotient they come in N_LPARTS groups of whole LogUp
@@ -126,6 +200,7 @@ def emit_cpp(machine):
         out.append("    template <int PART, class C> DVT_HD static void interactions_part(C &c) {")
         out.append("        using T = typename C::T; (void)sizeof(T); (void)c;")
         for k, (lo, hi) in enumerate(lparts):
+            names = Names()
             out.append(f"        if constexpr (PART == {k}) {{")
             seen = set()
             for j in range(lo, hi):
@@ -133,9 +208,9 @@ def emit_cpp(machine):
                 for e in topo([it.mult] + it.vals):
                     if e.id not in seen:
                         seen.add(e.id)
-                        out.append("            " + cpp_node(e))
-                vals = ", ".join(f"v{v.id}" for v in it.vals)
-                out.append(f"            {{ const T vals[] = {{{vals}}}; c.interaction({j}, {machine.buses[it.bus]}, {it.sign}, {SCOPE_ID[it.scope]}, v{it.mult.id}, vals, {len(it.vals)}); }}")
+                        out.append("            " + cpp_node(e, names))
+                vals = ", ".join(names(v) for v in it.vals)
+                out.append(f"            {{ const T vals[] = {{{vals}}}; c.interaction({j}, {machine.buses[it.bus]}, {it.sign}, {SCOPE_ID[it.scope]}, {names(it.mult)}, vals, {len(it.vals)}); }}")
             out.append("        }")
         out.append("    }")
         out.append("};")
@@ -151,8 +226,8 @@ def emit_cpp(machine):
 
 
 # ------------------------------------------------------------------ C (oracle)
-def c_node(e):
-    n = f"v{e.id}"
+def c_node(e, nm):
+    n = nm(e)
     if e.op == "const":
         return f"const bb_t {n} = {e.args[0]}u;"
     if e.op == "var":
@@ -161,7 +236,7 @@ def c_node(e):
             return f"const bb_t {n} = pub[{idx}];"
         arr = {"main": "main", "prep": "prep"}[kind] + ("_n" if rot else "_l")
         return f"const bb_t {n} = {arr}[{idx}];"
-    a = [f"v{x.id}" for x in e.args]
+    a = [nm(x) for x in e.args]
     if e.op == "add":
         return f"const bb_t {n} = bb_add({a[0]}, {a[1]});"
     if e.op == "sub":
@@ -181,10 +256,11 @@ def emit_c(machine):
         nm = f"{machine.name}_{ch.name}"
         out.append(f"static void {nm}_constraints(const bb_t *main_l, const bb_t *main_n, const bb_t *prep_l, const bb_t *prep_n, const bb_t *pub, bb_t *out) {{")
         out.append("    (void)main_l; (void)main_n; (void)prep_l; (void)prep_n; (void)pub;")
+        names = Names()
         for e in topo([e for e, _ in ch.constraints]):
-            out.append("    " + c_node(e))
+            out.append("    " + c_node(e, names))
         for i, (e, _) in enumerate(ch.constraints):
-            out.append(f"    out[{i}] = v{e.id};")
+            out.append(f"    out[{i}] = {names(e)};")
         out.append("}")
         max_ar = max([len(i.vals) for i in ch.interactions] + [1])
         out.append(f"static void {nm}_interactions(const bb_t *main_l, const bb_t *main_n, const bb_t *prep_l, const bb_t *prep_n, const bb_t *pub, bb_t *mult, bb_t *vals) {{")
@@ -193,12 +269,13 @@ def emit_c(machine):
         for it in ch.interactions:
             roots.append(it.mult)
             roots += it.vals
+        names = Names()
         for e in topo(roots):
-            out.append("    " + c_node(e))
+            out.append("    " + c_node(e, names))
         for j, it in enumerate(ch.interactions):
-            out.append(f"    mult[{j}] = v{it.mult.id};")
+            out.append(f"    mult[{j}] = {names(it.mult)};")
             for k, v in enumerate(it.vals):
-                out.append(f"    vals[{j * max_ar + k}] = v{v.id};")
+                out.append(f"    vals[{j * max_ar + k}] = {names(v)};")
         out.append("}")
         whens = ", ".join(str(WHEN_ID[w]) for _, w in ch.constraints) or "0"
         out.append(f"static const uint8_t {nm}_when[] = {{{whens}}};")

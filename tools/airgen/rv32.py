@@ -5,7 +5,7 @@ Chips
   program   preprocessed decoded instruction table, one row per instruction word
   byte      preprocessed 2^16-row byte-pair table: AND/OR/XOR/LTU/MSB/range lookups
   cpu       one row per executed instruction: fetch (program lookup), register
-            ports (registers live in the memory argument at addresses 0..31),
+            ports (registers live in the memory argument at addresses REG_BASE + 0..31),
             and every instruction family in a shared ("union") column block
   mem_image preprocessed initial memory image (registers = 0, ELF segments)
   mem_init  one row per initialised address, sorted: initial value at timestamp 0,
@@ -14,6 +14,10 @@ Chips
   muldiv    MULH/MULHSU/DIV/DIVU/REM/REMU rows, same bus (only in shards that use them)
   sha_extend  the SHA_EXTEND precompile (SHA-256 message schedule, 64 rows per call), fed over the sys bus
   sha_compress  the SHA_COMPRESS precompile (SHA-256 compression function, 80 rows per call), same bus
+  fp_op     BLS12-381 base-field add / sub / mul precompiles (one row per call), same bus
+  fp2_op    BLS12-381 Fp2 add / sub / mul precompiles (one row per call)
+  bls_g1    BLS12-381 G1 affine add / double precompiles (one row per call)
+  secp_k1   secp256k1 affine add / double precompiles (one row per call; the same short-Weierstrass a = 0 template)
 
 Memory consistency is an offline-checking LogUp multiset over tuples
 (addr, byte0..3, timestamp): every access consumes the previous tuple of its
@@ -48,6 +52,14 @@ SHA_K = [
     0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
     0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2]
 REG_A1 = 11
+# field / curve precompiles: SP1's syscall numbers as best recalled [EXTERNAL, unverified: the
+# sp1-core-executor crate is absent]; byte 1 = 1 "has a table" is what the cpu chip keys on, the chips receive the full code
+SYS_SECP256K1_ADD, SYS_SECP256K1_DOUBLE = 0x0001010A, 0x0000010B
+SYS_BLS12381_ADD, SYS_BLS12381_DOUBLE = 0x0001011E, 0x0000011F
+SYS_BLS12381_FP_ADD, SYS_BLS12381_FP_SUB, SYS_BLS12381_FP_MUL = 0x00010120, 0x00010121, 0x00010122
+SYS_BLS12381_FP2_ADD, SYS_BLS12381_FP2_SUB, SYS_BLS12381_FP2_MUL = 0x00010123, 0x00010124, 0x00010125
+BLS12381_P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+SECP256K1_P = (1 << 256) - (1 << 32) - 977
 
 # byte-table opcodes
 B_AND, B_OR, B_XOR, B_LTU, B_MSB, B_RANGE, B_U16, B_ADDR = 1, 2, 3, 4, 5, 6, 7, 8
@@ -81,6 +93,17 @@ UNION_W = 26
 # of an address and an address gap (both below it) stays below p = 2^31 - 2^27 + 1: the mem_init table's "strictly
 # increasing" check then holds over the integers, not only mod p.
 ADDR_TOP_BYTE = 0x38
+# The 32 registers are words of the memory argument at REG_BASE + r: ABOVE every address a load, a store or a precompile
+# can form (those are four range-checked bytes with a top byte below ADDR_TOP_BYTE), so no guest access can alias a
+# register (x0 stays 0 whatever pointer the guest dereferences) and nothing has to compare an address with 32.
+REG_BASE = ADDR_TOP_BYTE << 24
+# next_pc of a HALT row, and therefore of the last shard: a value no other row can produce (a sequential pc, a static
+# target and a JALR target are all below REG_BASE; p - 1, the JALR "target" 0 - 1, is not 2^30 either), so "the
+# execution halted" is bound to a HALT row, not to control flow that happens to reach address 0.
+HALT_PC = 1 << 30
+# aux (target) field of a JAL / branch whose static target lies outside the text (the executor traps there): an odd value,
+# never the pc of a program row, never HALT_PC
+BAD_PC = 1
 
 
 def build_program():
@@ -168,7 +191,7 @@ def build_cpu():
     # the receiving chip constrains a and range-checks its bytes
     ch.send("alu", [alu_op] + a + b + c, F["is_alu"])
 
-    # ---------------- register ports (memory bus, addresses 0..31)
+    # ---------------- register ports (memory bus, addresses REG_BASE + 0..31)
     def port(addr, prev_val, val, prev_sh, same, prev_ts, ts, lo, hi, en):
         # consume (addr, value, shard', clk'), produce (addr, value, shard, clk) with (shard', clk') < (shard, clk):
         # same shard -> clk - clk' - 1 is a 24-bit number; earlier shard -> shard - shard' - 1 is
@@ -179,9 +202,9 @@ def build_cpu():
         ch.assert_zero(en * (same * (ts - prev_ts - 1) + (1 - same) * (shard - prev_sh - 1) - lo - 65536 * hi))
         ch.send("byte", [B_U16, 0, lo, 0], en)
 
-    port(rs2, c, c, pc_sh, pc_same, pc_ts, clk, pc_lo, pc_hi, F["rs2_en"])
-    port(rs1, b, b, pb_sh, pb_same, pb_ts, clk + 1, pb_lo, pb_hi, F["rs1_en"])
-    port(rd, pa_prev, a, pa_sh, pa_same, pa_ts, clk + 3, pa_lo, pa_hi, F["rd_en"])
+    port(rs2 + REG_BASE, c, c, pc_sh, pc_same, pc_ts, clk, pc_lo, pc_hi, F["rs2_en"])
+    port(rs1 + REG_BASE, b, b, pb_sh, pb_same, pb_ts, clk + 1, pb_lo, pb_hi, F["rs1_en"])
+    port(rd + REG_BASE, pa_prev, a, pa_sh, pa_same, pa_ts, clk + 3, pa_lo, pa_hi, F["rd_en"])
     for i in range(4):
         ch.assert_zero(F["imm_c"] * (c[i] - imm[i]))
 
@@ -288,9 +311,10 @@ def build_cpu():
         ch.assert_zero(sel_adder * (b[i] + off[i] + cin - s[i] - 256 * acy[i]))
         ch.assert_zero(sel_adder * (acy[i] * (acy[i] - 1)))
     # range of the four sum bytes, address / target < 0x38000000, and the byte offset (low two address bits) in TWO lookups:
-    # [RANGE, 0, s1, s2] and [ADDR, offset, s0, s3] (byte-table op B_ADDR).  `offset` = o1 + 2 o2 + 3 o3 of the memory family
-    # below; on JALR rows those cells are free witnesses (the lookup makes them s0 & 3, nothing reads them); on MUL / MULHU
-    # rows (the bytes of x, plain range checks) the entry must be 0 and the cells are.
+    # [RANGE, 0, s1, s2] and [ADDR, offset, s0, s3] (byte-table op B_ADDR).  `offset` = o1 + 2 o2 + 3 o3, a one-hot value in
+    # 0..3 on every adder row (JALR included: with free cells the entry (s0 & 3) + 4 would pass for a top byte >= 0x38 and
+    # the target bound would not hold); on MUL / MULHU rows (the bytes of x, plain range checks) the entry must be 0 and
+    # the cells are.
     o_val = U[21] + 2 * U[22] + 3 * U[23]
     ch.send("byte", [B_RANGE, 0, s[1], s[2]], sel_adder + sel_mul)
     ch.send("byte", [B_ADDR * sel_adder + B_RANGE * sel_mul, o_val, s[0], s[3]], sel_adder + sel_mul)
@@ -307,8 +331,8 @@ def build_cpu():
     o0 = 1 - o1 - o2 - o3
     oh = [o0, o1, o2, o3]
     for x in (o1, o2, o3):
-        ch.assert_zero(sel_mem * (x * (x - 1)))
-    ch.assert_zero(sel_mem * ((o1 + o2 + o3) * (o1 + o2 + o3 - 1)))
+        ch.assert_zero(sel_adder * (x * (x - 1)))
+    ch.assert_zero(sel_adder * ((o1 + o2 + o3) * (o1 + o2 + o3 - 1)))
     # (offset = the low two address bits: the B_ADDR lookup above)
     ch.assert_zero((F["is_lw"] + F["is_sw"]) * (o1 + o2 + o3))                      # word access: aligned
     ch.assert_zero((F["is_lh"] + F["is_lhu"] + F["is_sh"]) * (o1 + o3))              # halfword access: even
@@ -366,7 +390,7 @@ def build_cpu():
     ch.assert_zero(ec * (is_halt * (is_halt - 1)))
     ch.assert_zero(ec * (is_halt * idw))
     ch.assert_zero(ec * (idw * id_inv - (1 - is_halt)))
-    ch.assert_zero(ec * (next_pc - (1 - is_halt) * (pc + 4)))
+    ch.assert_zero(ec * (next_pc - (1 - is_halt) * (pc + 4) - is_halt * HALT_PC))
     ch.assert_zero(ec * (is_halt * (word(c) - ch.pub(PUB_EXIT_CODE))))
     ch.assert_zero(ec * (is_halt * c[3]))        # exit codes are below 2^24: word(c) is the exit code itself, not a residue
     # only HINT_LEN (id 0xF0) returns a value in t0 (advice: the length of the next stdin buffer, private input like the
@@ -398,7 +422,7 @@ def build_cpu():
     ch.assert_zero(ec * (is_pre * (b[1] - 1)))
     ch.assert_zero(ec * ((b[1] - 1) * pre_inv - (1 - is_pre)))
     ch.assert_zero(sys_m - ec * (is_commit + is_pre))
-    ch.assert_zero(sys_m * (maddr - REG_A1))
+    ch.assert_zero(sys_m * (maddr - (REG_BASE + REG_A1)))
     for i in range(4):
         ch.assert_zero(sys_m * (mv[i] - mp[i]))
     ch.assert_zero(ec * (is_pre * (u_clk - clk)))
@@ -809,6 +833,211 @@ def build_sha_compress():
     return ch
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# Field and curve precompiles: one row per call.  Operands are little-endian byte vectors in guest memory (SP1's layout:
+# a BLS12-381 Fp element is 12 words, an affine point x || y).  A relation "V = 0 (mod p)" is proven as the INTEGER identity
+# V + OFF * p - q * p = 0 over byte limbs (dsl.Chip.assert_poly_zero): q is a witness of range-checked bytes, OFF a constant
+# that keeps q non-negative.  Every value written back is canonical (< p): the comparison is witnessed on 3-byte groups.
+def limbs_of(v, n):
+    assert 0 <= v < 1 << (8 * n)
+    return [(v >> (8 * i)) & 0xFF for i in range(n)]
+
+
+def groups3(vec):
+    """a byte vector as values of 3-byte groups (below 2^24: no wrap in the field)"""
+    return [esum((x * (1 << (8 * t)) if not isinstance(x, int) else Expr.const(x << (8 * t))) for t, x in enumerate(vec[g:g + 3])) for g in range(0, len(vec), 3)]
+
+
+def range_bytes(ch, vec, mult):
+    for i in range(0, len(vec) - 1, 2):
+        ch.send("byte", [B_RANGE, 0, vec[i], vec[i + 1]], mult)
+    if len(vec) % 2:
+        ch.send("byte", [B_RANGE, 0, vec[-1], 0], mult)
+
+
+def assert_lt_const(ch, name, vec, modulus, sel):
+    """vec (range-checked bytes) < modulus as integers, on rows where sel = 1: one-hot flag of the most significant 3-byte
+    group that differs, equality above it, and modulus_g - vec_g - 1 = a 24-bit number there."""
+    gv, gm = groups3(vec), groups3(limbs_of(modulus, len(vec)))
+    G = len(gv)
+    f = ch.cols(name + "_f", G)
+    d = ch.cols(name + "_d", 3)
+    for x in f:
+        ch.assert_zero(x * (x - 1))
+    ch.assert_eq(esum(f), sel)
+    for g in range(G):
+        ch.assert_zero((sel - esum(f[g:])) * (gv[g] - gm[g]))
+    ch.assert_zero(esum(f[g] * (gm[g] - gv[g] - 1) for g in range(G)) - (d[0] + 256 * d[1] + 65536 * d[2]))
+    ch.send("byte", [B_RANGE, 0, d[0], d[1]], sel)
+    ch.send("byte", [B_RANGE, 0, d[2], 0], sel)
+
+
+def assert_differ(ch, name, va, vb, sel):
+    """va != vb as integers (both canonical byte vectors) on rows where sel = 1: sum_g (va_g - vb_g) z_g = 1 has a
+    solution exactly when some 3-byte group differs"""
+    ga, gb = groups3(va), groups3(vb)
+    z = ch.cols(name + "_z", len(ga))
+    ch.assert_zero(esum((ga[g] - gb[g]) * z[g] for g in range(len(ga))) - sel)
+
+
+def mem_words(ch, name, ptr, old, new, shard, ts, mult):
+    """len(old) / 4 consecutive words at the word-aligned pointer `ptr` (four bytes): each is consumed with the (shard, clk)
+    of its previous access and produced with (shard, ts); old = new for a read"""
+    n = len(old) // 4
+    his = []
+    for k in range(n):
+        m_sh, m_ts, m_same, m_lo, m_hi = (ch.col(f"{name}_{t}[{k}]") for t in ("sh", "ts", "same", "lo", "hi"))
+        addr = word(ptr) + 4 * k
+        ch.receive("mem", [addr] + old[4 * k:4 * k + 4] + [m_sh, m_ts], mult)
+        ch.send("mem", [addr] + new[4 * k:4 * k + 4] + [shard, ts], mult)
+        ch.assert_zero(mult * (m_same * (m_same - 1)))
+        ch.assert_zero(mult * (m_same * (shard - m_sh)))
+        ch.assert_zero(mult * (m_same * (ts - m_ts - 1) + (1 - m_same) * (shard - m_sh - 1) - m_lo - 65536 * m_hi))
+        ch.send("byte", [B_U16, 0, m_lo, 0], mult)
+        his.append(m_hi)
+    range_bytes(ch, his, mult)
+
+
+def code_bytes(sel_codes):
+    """the four bytes of the syscall code as affine expressions of the operation selectors"""
+    return [esum(s * ((c >> (8 * i)) & 0xFF) for s, c in sel_codes) for i in range(4)]
+
+
+def build_fp_op():
+    """BLS12381_FP_ADD / _SUB / _MUL (a0 = x, a1 = y: 12 little-endian words each): x := x op y mod p.  Operands need not be
+    reduced; the result is.  y is read at (shard, clk + 2), x read and replaced at (shard, clk + 3) (so x may be y)."""
+    L, Pm = 48, BLS12381_P
+    ch = Chip("fp_op")
+    shard = ch.pub(PUB_SHARD)
+    is_real, is_add, is_sub, is_mul, clk = ch.col("is_real"), ch.col("is_add"), ch.col("is_sub"), ch.col("is_mul"), ch.col("clk")
+    xp, yp = ch.cols("xp", 4), ch.cols("yp", 4)
+    x, y, r, q = ch.cols("x", L), ch.cols("y", L), ch.cols("r", L), ch.cols("q", L + 1)
+    for f in (is_real, is_add, is_sub, is_mul):
+        ch.assert_bool(f)
+    ch.assert_eq(is_add + is_sub + is_mul, is_real)
+    ch.assert_zero(is_real.next() * (1 - is_real), "trans")
+    ch.receive("sys", code_bytes([(is_add, SYS_BLS12381_FP_ADD), (is_sub, SYS_BLS12381_FP_SUB), (is_mul, SYS_BLS12381_FP_MUL)]) + xp + yp + [clk, shard], is_real)
+    ch.send("byte", [B_ADDR, 0, xp[0], xp[3]], is_real)
+    ch.send("byte", [B_ADDR, 0, yp[0], yp[3]], is_real)
+    mem_words(ch, "my", yp, y, y, shard, clk + 2, is_real)
+    mem_words(ch, "mx", xp, x, r, shard, clk + 3, is_real)
+    range_bytes(ch, r, is_real)
+    range_bytes(ch, q, is_real)
+    assert_lt_const(ch, "rlt", r, Pm, is_real)
+    Pl = limbs_of(Pm, L)
+    w = ch.assert_poly_zero("rel", [
+        (1, is_mul, x, y), (1, is_add, x, None), (1, is_add, y, None),
+        (1, is_sub, x, None), (-1, is_sub, y, None), (10, is_sub, Pl, None),       # x - y + 10 p >= 0 for any 384-bit y
+        (-1, is_real, r, None), (-1, is_real, q, Pl)],
+        is_real, [{is_real.id: 1, s.id: 1} for s in (is_add, is_sub, is_mul)])
+    for t in w:
+        ch.send("byte", [B_U16, 0, t, 0], is_real)
+    ch.quotient_parts = 1
+    ch.logup_parts = 10
+    return ch
+
+
+def build_fp2_op():
+    """BLS12381_FP2_ADD / _SUB / _MUL (a0 = x, a1 = y: c0 || c1, 24 words each): x := x op y in Fp2 = Fp[u] / (u^2 + 1)."""
+    L, Pm = 48, BLS12381_P
+    ch = Chip("fp2_op")
+    shard = ch.pub(PUB_SHARD)
+    is_real, is_add, is_sub, is_mul, clk = ch.col("is_real"), ch.col("is_add"), ch.col("is_sub"), ch.col("is_mul"), ch.col("clk")
+    xp, yp = ch.cols("xp", 4), ch.cols("yp", 4)
+    x0, x1, y0, y1 = ch.cols("x0", L), ch.cols("x1", L), ch.cols("y0", L), ch.cols("y1", L)
+    r0, r1, q0, q1 = ch.cols("r0", L), ch.cols("r1", L), ch.cols("q0", L + 1), ch.cols("q1", L + 1)
+    for f in (is_real, is_add, is_sub, is_mul):
+        ch.assert_bool(f)
+    ch.assert_eq(is_add + is_sub + is_mul, is_real)
+    ch.assert_zero(is_real.next() * (1 - is_real), "trans")
+    ch.receive("sys", code_bytes([(is_add, SYS_BLS12381_FP2_ADD), (is_sub, SYS_BLS12381_FP2_SUB), (is_mul, SYS_BLS12381_FP2_MUL)]) + xp + yp + [clk, shard], is_real)
+    ch.send("byte", [B_ADDR, 0, xp[0], xp[3]], is_real)
+    ch.send("byte", [B_ADDR, 0, yp[0], yp[3]], is_real)
+    mem_words(ch, "my", yp, y0 + y1, y0 + y1, shard, clk + 2, is_real)
+    mem_words(ch, "mx", xp, x0 + x1, r0 + r1, shard, clk + 3, is_real)
+    for v in (r0, r1, q0, q1):
+        range_bytes(ch, v, is_real)
+    assert_lt_const(ch, "r0lt", r0, Pm, is_real)
+    assert_lt_const(ch, "r1lt", r1, Pm, is_real)
+    Pl = limbs_of(Pm, L)
+    OFF = limbs_of(1 << 388, L + 1)          # x1 y1 < 2^768 < 2^388 p
+    cases = [{is_real.id: 1, s.id: 1} for s in (is_add, is_sub, is_mul)]
+    w0 = ch.assert_poly_zero("rel0", [
+        (1, is_mul, x0, y0), (-1, is_mul, x1, y1), (1, is_mul, OFF, Pl),
+        (1, is_add, x0, None), (1, is_add, y0, None), (1, is_sub, x0, None), (-1, is_sub, y0, None), (10, is_sub, Pl, None),
+        (-1, is_real, r0, None), (-1, is_real, q0, Pl)], is_real, cases)
+    w1 = ch.assert_poly_zero("rel1", [
+        (1, is_mul, x0, y1), (1, is_mul, x1, y0),
+        (1, is_add, x1, None), (1, is_add, y1, None), (1, is_sub, x1, None), (-1, is_sub, y1, None), (10, is_sub, Pl, None),
+        (-1, is_real, r1, None), (-1, is_real, q1, Pl)], is_real, cases)
+    for t in w0 + w1:
+        ch.send("byte", [B_U16, 0, t, 0], is_real)
+    ch.quotient_parts = 1
+    ch.logup_parts = 20
+    return ch
+
+
+def build_weierstrass(name, L, Pm, code_add, code_dbl):
+    """Affine point addition / doubling on y^2 = x^3 + b over F_p (a = 0: BLS12-381 G1 and secp256k1 alike).
+    a0 = p (x || y, L / 4 little-endian words each), a1 = q for ADD, 0 for DOUBLE;  p := p + q  /  p := 2 p.
+    Witness lambda, x3, y3 (range-checked bytes) with
+        ADD     lambda (x2 - x1) = y2 - y1          DOUBLE   2 lambda y1 = 3 x1^2          (mod p)
+                x3 = lambda^2 - x1 - x2                      x3 = lambda^2 - 2 x1
+                y3 = lambda (x1 - x3) - y1                   y3 = lambda (x1 - x3) - y1
+    All coordinates read are canonical (< p, checked), so are x3 and y3.  ADD requires x1 != x2 (witnessed: with equal
+    abscissae lambda would be unconstrained); neither operation knows the point at infinity: the guest handles p = +-q and
+    p = 0 itself, as with SP1's precompiles.  q is read at (shard, clk + 2), p read and replaced at (shard, clk + 3)."""
+    ch = Chip(name)
+    shard = ch.pub(PUB_SHARD)
+    is_real, is_add, is_dbl, clk = ch.col("is_real"), ch.col("is_add"), ch.col("is_dbl"), ch.col("clk")
+    pp, qp = ch.cols("pp", 4), ch.cols("qp", 4)
+    x1, y1, x2, y2 = ch.cols("x1", L), ch.cols("y1", L), ch.cols("x2", L), ch.cols("y2", L)
+    lam, x3, y3 = ch.cols("lam", L), ch.cols("x3", L), ch.cols("y3", L)
+    q1, q2, q3 = ch.cols("q1", L + 1), ch.cols("q2", L + 1), ch.cols("q3", L + 1)
+    for f in (is_real, is_add, is_dbl):
+        ch.assert_bool(f)
+    ch.assert_eq(is_add + is_dbl, is_real)
+    ch.assert_zero(is_real.next() * (1 - is_real), "trans")
+    for i in range(4):
+        ch.assert_zero(is_dbl * qp[i])                   # DOUBLE: a1 = 0
+    ch.receive("sys", code_bytes([(is_add, code_add), (is_dbl, code_dbl)]) + pp + qp + [clk, shard], is_real)
+    ch.send("byte", [B_ADDR, 0, pp[0], pp[3]], is_real)
+    ch.send("byte", [B_ADDR, 0, qp[0], qp[3]], is_add)
+    mem_words(ch, "mq", qp, x2 + y2, x2 + y2, shard, clk + 2, is_add)
+    mem_words(ch, "mp", pp, x1 + y1, x3 + y3, shard, clk + 3, is_real)
+    for v in (lam, x3, y3, q1, q2, q3):
+        range_bytes(ch, v, is_real)
+    for nm_, v, s in (("x1lt", x1, is_real), ("y1lt", y1, is_real), ("x2lt", x2, is_add), ("y2lt", y2, is_add), ("x3lt", x3, is_real), ("y3lt", y3, is_real)):
+        assert_lt_const(ch, nm_, v, Pm, s)
+    assert_differ(ch, "xne", x1, x2, is_add)
+    Pl = limbs_of(Pm, L)
+    M = 1 << (8 * L)
+    cases = [{is_real.id: 1, s.id: 1} for s in (is_add, is_dbl)]
+    w1 = ch.assert_poly_zero("rel1", [
+        (1, is_add, lam, x2), (-1, is_add, lam, x1), (-1, is_add, y2, None), (1, is_add, y1, None),
+        (2, is_dbl, lam, y1), (-3, is_dbl, x1, x1),
+        (1, is_real, limbs_of(4 * M, L + 1), Pl), (-1, is_real, q1, Pl)], is_real, cases)
+    w2 = ch.assert_poly_zero("rel2", [
+        (1, is_real, lam, lam), (-1, is_real, x1, None), (-1, is_add, x2, None), (-1, is_dbl, x1, None), (-1, is_real, x3, None),
+        (4, is_real, Pl, None), (-1, is_real, q2, Pl)], is_real, cases)
+    w3 = ch.assert_poly_zero("rel3", [
+        (1, is_real, lam, x1), (-1, is_real, lam, x3), (-1, is_real, y1, None), (-1, is_real, y3, None),
+        (1, is_real, limbs_of(2 * M, L + 1), Pl), (-1, is_real, q3, Pl)], is_real, cases)
+    for t in w1 + w2 + w3:
+        ch.send("byte", [B_U16, 0, t, 0], is_real)
+    ch.quotient_parts = 1
+    ch.logup_parts = 24 if L == 48 else 16
+    return ch
+
+
+def build_bls_g1():
+    return build_weierstrass("bls_g1", 48, BLS12381_P, SYS_BLS12381_ADD, SYS_BLS12381_DOUBLE)
+
+
+def build_secp_k1():
+    return build_weierstrass("secp_k1", 32, SECP256K1_P, SYS_SECP256K1_ADD, SYS_SECP256K1_DOUBLE)
+
+
 def build_mem_image():
     ch = Chip("mem_image")
     addr, v, real = ch.prep("addr"), ch.preps("v", 4), ch.prep("is_real")
@@ -830,12 +1059,13 @@ def build_mem_init():
     ch.assert_bool(is_img)
     ch.assert_zero(is_img * (1 - is_real))
     ch.assert_zero(is_real.next() * (1 - is_real), "trans")
-    # strictly increasing addresses OVER THE INTEGERS: the address itself is four range-checked bytes below 0x38000000,
-    # so is the gap d = addr' - addr - 1, hence addr + 1 + d < 2 * 0x38000000 < p cannot wrap (one initial tuple per address)
+    # strictly increasing addresses OVER THE INTEGERS: the address itself is four range-checked bytes below 0x39000000
+    # (guest memory below 0x38000000, then the registers), the gap d = addr' - addr - 1 four bytes below 0x38000000,
+    # hence addr + 1 + d < 0x71000000 < p cannot wrap (one initial tuple per address)
     ch.assert_zero(is_real.next() * (addr_next - addr - 1 - word([x.next() for x in d])), "trans")
     ch.send("byte", [B_RANGE, 0, ab[0], ab[1]], is_real)
     ch.send("byte", [B_RANGE, 0, ab[2], ab[3]], is_real)
-    ch.send("byte", [B_LTU, 1, ab[3], ADDR_TOP_BYTE], is_real)
+    ch.send("byte", [B_LTU, 1, ab[3], ADDR_TOP_BYTE + 1], is_real)     # (+ 1: the registers at REG_BASE .. REG_BASE + 31)
     ch.send("byte", [B_RANGE, 0, d[0], d[1]], is_real)
     ch.send("byte", [B_RANGE, 0, d[2], d[3]], is_real)
     ch.send("byte", [B_LTU, 1, d[3], ADDR_TOP_BYTE], is_real)
