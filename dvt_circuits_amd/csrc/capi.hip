@@ -676,7 +676,7 @@ static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_buf
                             ec = pl.exit_code;
                         }
                         std::string e;
-                        if (!pl.abort && !rv32::build_aux_host(r.meta, so.alu, so.sha_ext, so.sha_cmp, rows, ec, pk->prep, &r.aux, &e)) r.err = e;
+                        if (!pl.abort && !rv32::build_aux_host(r.meta, so.alu, so.sha_ext, so.sha_cmp, so.big, rows, ec, pk->prep, &r.aux, &e)) r.err = e;
                     }
                 }
                 std::lock_guard<std::mutex> lk(pl.mu);

@@ -43,13 +43,18 @@ constexpr uint32_t SYS_COMMIT = 0x10;
 constexpr uint32_t SYS_SHA_EXTEND = 0x00300105u;  // SP1 syscall code (byte 1 = 1: the call has a precompile table)
 constexpr uint32_t SYS_SHA_COMPRESS = 0x00010106u;
 constexpr uint32_t REG_A1 = 11;
-constexpr uint32_t REG_BASE = ADDR_LIMIT;     // the registers are words REG_BASE + 0..31 of the memory argument: above every guest address
+constexpr uint32_t REG_BASE = ADDR_LIMIT + (1u << 23);   // the registers are words REG_BASE + 0..31 of the memory argument: above every guest address (and every multi-word precompile access that starts below ADDR_LIMIT)
 constexpr uint32_t HALT_PC = 1u << 30;        // next_pc of a HALT row (tools/airgen/rv32.py): no other row can produce it
 constexpr uint32_t BAD_PC = 1;                // program-table target of a JAL / branch whose static target lies outside the text
 constexpr uint32_t MAX_SHARDS = 65535;        // shard numbers travel as 16-bit halves of the cycle records
 constexpr uint32_t ALU_SLL = 1, ALU_SRL = 2, ALU_SRA = 3;  // alu-bus opcodes (chips outside the cpu chip): shift chip
 constexpr uint32_t ALU_MULH = 4, ALU_MULHSU = 5, ALU_DIV = 6, ALU_DIVU = 7, ALU_REM = 8, ALU_REMU = 9;  // muldiv chip
-constexpr int N_CHIPS = 9;  // program, byte, cpu, mem_image, mem_init, shift, muldiv, sha_extend, sha_compress
+constexpr int N_CHIPS = 13;  // program, byte, cpu, mem_image, mem_init, shift, muldiv, sha_extend, sha_compress, fp_op, fp2_op, bls_g1, secp_k1
+// field / curve precompiles (SP1's syscall numbers as best recalled [EXTERNAL, unverified]; tools/airgen/rv32.py)
+constexpr uint32_t SYS_SECP256K1_ADD = 0x0001010Au, SYS_SECP256K1_DOUBLE = 0x0000010Bu;
+constexpr uint32_t SYS_BLS12381_ADD = 0x0001011Eu, SYS_BLS12381_DOUBLE = 0x0000011Fu;
+constexpr uint32_t SYS_BLS12381_FP_ADD = 0x00010120u, SYS_BLS12381_FP_SUB = 0x00010121u, SYS_BLS12381_FP_MUL = 0x00010122u;
+constexpr uint32_t SYS_BLS12381_FP2_ADD = 0x00010123u, SYS_BLS12381_FP2_SUB = 0x00010124u, SYS_BLS12381_FP2_MUL = 0x00010125u;
 constexpr uint32_t N_PUBLIC = 5;  // start_pc, next_pc, exit_code, shard, is_last
 
 // dense dispatch code of the interpreter (one case per instruction form: which ports it drives is static per case)
@@ -143,10 +148,28 @@ struct ShaCmpEvent {
     uint32_t w[64], hs[8], w_ts[64], h_ts[8];
     uint16_t w_sh[64], h_sh[8];
 };
+// one field / curve precompile call: a0 = pointer to the operand that is replaced by the result (read and written at
+// clk + 3), a1 = pointer to the second operand (read at clk + 2; absent for DOUBLE).  Little-endian words.
+constexpr int BIGOP_MAX_WORDS = 24;
+struct BigOpEvent {
+    uint32_t code, clk, a_ptr, b_ptr;
+    uint32_t a[BIGOP_MAX_WORDS], b[BIGOP_MAX_WORDS], r[BIGOP_MAX_WORDS];
+    uint32_t lam[BIGOP_MAX_WORDS / 2];                  // curve operations: the slope (canonical)
+    uint32_t a_ts[BIGOP_MAX_WORDS], b_ts[BIGOP_MAX_WORDS];
+    uint16_t a_sh[BIGOP_MAX_WORDS], b_sh[BIGOP_MAX_WORDS];
+};
+// static shape of a call: the chip that proves it, words of the two operands (words_b = 0: a1 must be 0)
+struct BigOpInfo {
+    int chip, words_a, words_b;
+};
+bool bigop_info(uint32_t code, BigOpInfo *out);
+// r (and lam for curve operations) from a and b; nullptr or the reason the call traps (non-canonical coordinates, ...)
+const char *bigop_compute(uint32_t code, const uint32_t *a, const uint32_t *b, uint32_t *r, uint32_t *lam);
 struct ShardRec {
     std::vector<AluEvent> alu;   // instructions of this shard proven by chips outside the cpu chip
     std::vector<ShaExtEvent> sha_ext;   // precompile calls of this shard
     std::vector<ShaCmpEvent> sha_cmp;
+    std::vector<BigOpEvent> big;
     uint32_t index = 0, start_pc = 0, next_pc = 0;
     std::vector<CycleRec> recs;
 };
@@ -202,6 +225,7 @@ struct ShardOut {
     std::vector<AluEvent> alu;
     std::vector<ShaExtEvent> sha_ext;
     std::vector<ShaCmpEvent> sha_cmp;
+    std::vector<BigOpEvent> big;
     uint32_t index = 0, start_pc = 0, next_pc = 0;
 };
 
@@ -476,7 +500,11 @@ struct ShardMeta {
     size_t n_recs;
 };
 bool build_aux_host(const ShardMeta &meta, const std::vector<AluEvent> &alu, const std::vector<ShaExtEvent> &sha_ext,
-                    const std::vector<ShaCmpEvent> &sha_cmp, const std::vector<MemInitRow> *mem_rows, int exit_code, const HostPrep &prep, HostTraces *out, std::string *err);
+                    const std::vector<ShaCmpEvent> &sha_cmp, const std::vector<BigOpEvent> &big, const std::vector<MemInitRow> *mem_rows, int exit_code,
+                    const HostPrep &prep, HostTraces *out, std::string *err);
+// the rows of the fp_op / fp2_op / bls_g1 / secp_k1 chips for the calls of one shard (rv32_bigops.hip); byte_mult[op][65536]
+// receives the byte-table lookups those rows make
+bool build_bigop_traces(const std::vector<BigOpEvent> &big, uint32_t shard, HostTraces *out, uint32_t *byte_mult, std::string *err);
 // the whole shard on the host, cpu chip included (debug C-ABI, tests)
 bool build_traces_host(const Program &prog, const ExecResult &res, size_t shard_pos, const HostPrep &prep, HostTraces *out, std::string *err);
 // instruction index -> row of the program table (provable instructions only; others map to row 0 and never occur)

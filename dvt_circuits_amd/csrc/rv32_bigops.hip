@@ -1,0 +1,275 @@
+// Field / curve precompiles of the rv32 machine (SP1's BLS12381_FP_*, BLS12381_FP2_*,
+// BLS12381_ADD / _DOUBLE, SECP256K1_ADD / _DOUBLE syscalls, which the reference's guests reach through the patched
+// bls12_381 / secp256k1 crates, reference crates/dkg/Cargo.toml:24-25): what a call computes (the guest machine's
+// semantics) and the rows of the four chips that prove the calls (tools/airgen/rv32.py: build_fp_op, build_fp2_op,
+// build_weierstrass).  Host code only.
+#include <string>
+#include <vector>
+
+#include "bigfield.h"
+#include "rv32.h"
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+#pragma clang optimize off
+#include "gen/air_rv32.inc"
+#pragma clang optimize on
+#include "gen/rv32_rels.h"
+
+namespace dvt {
+namespace rv32 {
+
+// ------------------------------------------------------------------ the fields
+static const uint64_t BLS_P[6] = {0xb9feffffffffaaabull, 0x1eabfffeb153ffffull, 0x6730d2a0f6b0f624ull, 0x64774b84f38512bfull, 0x4b1ba7b6434bacd7ull, 0x1a0111ea397fe69aull};
+static const uint64_t SECP_P[4] = {0xfffffffefffffc2full, 0xffffffffffffffffull, 0xffffffffffffffffull, 0xffffffffffffffffull};
+static const MontField<6> &bls() { static const MontField<6> f(BLS_P); return f; }
+static const MontField<4> &secp() { static const MontField<4> f(SECP_P); return f; }
+
+template <int N> static void load(uint64_t *o, const uint32_t *w) { for (int i = 0; i < N; i++) o[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32); }
+template <int N> static void store(uint32_t *w, const uint64_t *a) { for (int i = 0; i < N; i++) { w[2 * i] = (uint32_t)a[i]; w[2 * i + 1] = (uint32_t)(a[i] >> 32); } }
+
+bool bigop_info(uint32_t code, BigOpInfo *out) {
+    switch (code) {
+    case SYS_BLS12381_FP_ADD: case SYS_BLS12381_FP_SUB: case SYS_BLS12381_FP_MUL: *out = {RV32_CHIP_FP_OP, 12, 12}; return true;
+    case SYS_BLS12381_FP2_ADD: case SYS_BLS12381_FP2_SUB: case SYS_BLS12381_FP2_MUL: *out = {RV32_CHIP_FP2_OP, 24, 24}; return true;
+    case SYS_BLS12381_ADD: *out = {RV32_CHIP_BLS_G1, 24, 24}; return true;
+    case SYS_BLS12381_DOUBLE: *out = {RV32_CHIP_BLS_G1, 24, 0}; return true;
+    case SYS_SECP256K1_ADD: *out = {RV32_CHIP_SECP_K1, 16, 16}; return true;
+    case SYS_SECP256K1_DOUBLE: *out = {RV32_CHIP_SECP_K1, 16, 0}; return true;
+    default: return false;
+    }
+}
+
+// x op y mod p for arbitrary N-limb x, y (Montgomery conversion reduces them)
+template <int N>
+static void field_op(const MontField<N> &F, int op, const uint32_t *x, const uint32_t *y, uint32_t *r) {
+    uint64_t a[N], b[N], c[N];
+    load<N>(a, x); load<N>(b, y);
+    F.to_mont(a, a); F.to_mont(b, b);
+    if (op == 0) F.add(c, a, b);
+    else if (op == 1) F.sub(c, a, b);
+    else F.mul(c, a, b);
+    F.from_mont(c, c);
+    store<N>(r, c);
+}
+
+// affine add (q != nullptr) / double on y^2 = x^3 + b (a = 0); coordinates canonical; no point at infinity
+template <int N>
+static const char *curve_op(const MontField<N> &F, const uint32_t *p, const uint32_t *q, uint32_t *r, uint32_t *lam_out) {
+    uint64_t x1[N], y1[N], x2[N], y2[N], num[N], den[N], lam[N], x3[N], y3[N], t[N];
+    load<N>(x1, p); load<N>(y1, p + 2 * N);
+    if (!F.is_canonical(x1) || !F.is_canonical(y1)) return "curve precompile: coordinate of p not reduced";
+    if (q) {
+        load<N>(x2, q); load<N>(y2, q + 2 * N);
+        if (!F.is_canonical(x2) || !F.is_canonical(y2)) return "curve precompile: coordinate of q not reduced";
+        if (F.cmp(x1, x2) == 0) return "ADD precompile with equal abscissae (p = q or p = -q: the guest must handle those)";
+    } else if (F.is_zero(y1)) return "DOUBLE precompile of a point with y = 0";
+    F.to_mont(x1, x1); F.to_mont(y1, y1);
+    if (q) {
+        F.to_mont(x2, x2); F.to_mont(y2, y2);
+        F.sub(num, y2, y1); F.sub(den, x2, x1);
+    } else {
+        F.mul(t, x1, x1); F.add(num, t, t); F.add(num, num, t);   // 3 x1^2
+        F.add(den, y1, y1);
+        memcpy(x2, x1, sizeof x1);
+    }
+    F.inv(den, den);
+    F.mul(lam, num, den);
+    F.mul(x3, lam, lam); F.sub(x3, x3, x1); F.sub(x3, x3, x2);
+    F.sub(t, x1, x3); F.mul(y3, lam, t); F.sub(y3, y3, y1);
+    F.from_mont(lam, lam); F.from_mont(x3, x3); F.from_mont(y3, y3);
+    store<N>(r, x3); store<N>(r + 2 * N, y3); store<N>(lam_out, lam);
+    return nullptr;
+}
+
+const char *bigop_compute(uint32_t code, const uint32_t *a, const uint32_t *b, uint32_t *r, uint32_t *lam) {
+    switch (code) {
+    case SYS_BLS12381_FP_ADD: case SYS_BLS12381_FP_SUB: case SYS_BLS12381_FP_MUL:
+        field_op<6>(bls(), (int)(code - SYS_BLS12381_FP_ADD), a, b, r);
+        return nullptr;
+    case SYS_BLS12381_FP2_ADD: case SYS_BLS12381_FP2_SUB:
+        field_op<6>(bls(), (int)(code - SYS_BLS12381_FP2_ADD), a, b, r);
+        field_op<6>(bls(), (int)(code - SYS_BLS12381_FP2_ADD), a + 12, b + 12, r + 12);
+        return nullptr;
+    case SYS_BLS12381_FP2_MUL: {   // (a0 + a1 u)(b0 + b1 u), u^2 = -1
+        uint32_t t0[12], t1[12];
+        field_op<6>(bls(), 2, a, b, t0); field_op<6>(bls(), 2, a + 12, b + 12, t1);
+        field_op<6>(bls(), 1, t0, t1, r);
+        field_op<6>(bls(), 2, a, b + 12, t0); field_op<6>(bls(), 2, a + 12, b, t1);
+        field_op<6>(bls(), 0, t0, t1, r + 12);
+        return nullptr;
+    }
+    case SYS_BLS12381_ADD: return curve_op<6>(bls(), a, b, r, lam);
+    case SYS_BLS12381_DOUBLE: return curve_op<6>(bls(), a, nullptr, r, lam);
+    case SYS_SECP256K1_ADD: return curve_op<4>(secp(), a, b, r, lam);
+    case SYS_SECP256K1_DOUBLE: return curve_op<4>(secp(), a, nullptr, r, lam);
+    default: return "unknown syscall";
+    }
+}
+
+// ------------------------------------------------------------------ rows
+namespace {
+struct RowRef {
+    uint32_t *m; size_t n, row;
+    uint32_t get(int col) const { return m[(size_t)col * n + row]; }
+    void put(int col, uint32_t v) { m[(size_t)col * n + row] = v; }
+    void bytes(int col0, const uint32_t *w, int nwords) {
+        for (int k = 0; k < nwords; k++)
+            for (int i = 0; i < 4; i++) put(col0 + 4 * k + i, (w[k] >> (8 * i)) & 0xffu);
+    }
+};
+// walks the generated interactions of a chip on one (host) row and counts its byte-table lookups
+struct LookupCtx {
+    using T = Fp;
+    const RowRef &r;
+    const uint32_t *pubs;
+    uint32_t *byte_mult;
+    static T K(uint32_t monty) { return Fp::raw(monty); }
+    static T KI(uint32_t canonical) { return Fp::from_canonical(canonical); }
+    T main(int c, int rot) const { (void)rot; return Fp::from_canonical(r.get(c)); }   // (the precompile chips' interactions read the local row only)
+    T prep(int, int) const { return Fp::zero(); }
+    T pub(int k) const { return Fp::from_canonical(pubs[k]); }
+    void interaction(int, int bus, int sign, int, const T &mult, const T *vals, int) {
+        if (bus != 2 || sign < 0) return;   // bus 2 = byte (tools/airgen/rv32.py BUSES)
+        const uint32_t m = mult.canonical();
+        if (!m) return;
+        const uint32_t op = vals[0].canonical(), b = vals[2].canonical(), c = vals[3].canonical();
+        byte_mult[(size_t)(op - 1) * 65536 + (op == B_U16 ? b : (b << 8) | c)] += m;
+    }
+};
+
+static uint32_t ceil_log2(size_t n) { uint32_t l = 0; while (((size_t)1 << l) < n) l++; return l; }
+
+// the (shard, clk) a word carried before the access at (shard, ts): same-shard flag and the two limbs of the gap
+static void mem_meta(RowRef &R, int col_sh0, int k, uint32_t psh, uint32_t pts, uint32_t shard, uint32_t ts) {
+    const uint32_t d = psh == shard ? ts - pts - 1 : shard - psh - 1;
+    const int c = col_sh0 + 5 * k;   // sh, ts, same, lo, hi of word k are consecutive columns
+    R.put(c, psh); R.put(c + 1, pts); R.put(c + 2, psh == shard); R.put(c + 3, d & 0xffff); R.put(c + 4, d >> 16);
+}
+// v < modulus witnessed on 3-byte groups: one-hot flag of the most significant differing group, modulus_g - v_g - 1 there
+static bool fill_lt(RowRef &R, int col_f0, int col_d0, int col_v0, int L, const uint8_t *mod) {
+    const int G = (L + 2) / 3;
+    for (int g = G - 1; g >= 0; g--) {
+        uint32_t vg = 0, mg = 0;
+        for (int t = 0; t < 3 && 3 * g + t < L; t++) { vg |= R.get(col_v0 + 3 * g + t) << (8 * t); mg |= (uint32_t)mod[3 * g + t] << (8 * t); }
+        if (vg == mg) continue;
+        if (vg > mg) return false;
+        const uint32_t d = mg - vg - 1;
+        R.put(col_f0 + g, 1);
+        R.put(col_d0, d & 0xff); R.put(col_d0 + 1, (d >> 8) & 0xff); R.put(col_d0 + 2, d >> 16);
+        return true;
+    }
+    return false;   // equal to the modulus
+}
+static bool fill_differ(RowRef &R, int col_z0, int col_a0, int col_b0, int L) {
+    const int G = (L + 2) / 3;
+    for (int g = 0; g < G; g++) {
+        uint32_t ag = 0, bg = 0;
+        for (int t = 0; t < 3 && 3 * g + t < L; t++) { ag |= R.get(col_a0 + 3 * g + t) << (8 * t); bg |= R.get(col_b0 + 3 * g + t) << (8 * t); }
+        if (ag == bg) continue;
+        R.put(col_z0 + g, inv(Fp::from_canonical(ag) - Fp::from_canonical(bg)).canonical());
+        return true;
+    }
+    return false;
+}
+
+template <class Air>
+static bool finish_row(RowRef &R, const PolyRelDesc *rels, int nrels, const uint32_t *pubs, uint32_t *byte_mult, std::string *err) {
+    for (int i = 0; i < nrels; i++)
+        if (!solve_poly_rel(rels[i], R)) { if (err) *err = std::string("precompile row: identity '") + rels[i].name + "' has no witness"; return false; }
+    LookupCtx ctx{R, pubs, byte_mult};
+    Air::interactions(ctx);
+    return true;
+}
+
+struct WCols {   // column ids of a short-Weierstrass chip
+    int is_real, is_add, is_dbl, clk, pp, qp, x1, y1, x2, y2, lam, x3, y3, mq_sh, mp_sh;
+    int x1lt_f, x1lt_d, y1lt_f, y1lt_d, x2lt_f, x2lt_d, y2lt_f, y2lt_d, x3lt_f, x3lt_d, y3lt_f, y3lt_d, xne_z;
+};
+#define DVT_WCOLS(P) WCols{P##is_real, P##is_add, P##is_dbl, P##clk, P##pp_0, P##qp_0, P##x1_0, P##y1_0, P##x2_0, P##y2_0, P##lam_0, P##x3_0, P##y3_0, \
+                           P##mq_sh_0, P##mp_sh_0, P##x1lt_f_0, P##x1lt_d_0, P##y1lt_f_0, P##y1lt_d_0, P##x2lt_f_0, P##x2lt_d_0, P##y2lt_f_0, P##y2lt_d_0, \
+                           P##x3lt_f_0, P##x3lt_d_0, P##y3lt_f_0, P##y3lt_d_0, P##xne_z_0}
+}  // namespace
+
+bool build_bigop_traces(const std::vector<BigOpEvent> &big, uint32_t shard, HostTraces *out, uint32_t *byte_mult, std::string *err) {
+    HostTraces &T = *out;
+    std::vector<const BigOpEvent *> by_chip[N_CHIPS];
+    for (auto &e : big) {
+        BigOpInfo bi;
+        if (!bigop_info(e.code, &bi)) { if (err) *err = "precompile event with an unknown code"; return false; }
+        by_chip[bi.chip].push_back(&e);
+    }
+    const uint32_t pubs[N_PUBLIC] = {0, 0, 0, shard, 0};   // (the chips read PUB_SHARD only)
+    static const int widths[N_CHIPS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, RV32_FP_OP_MAIN_W, RV32_FP2_OP_MAIN_W, RV32_BLS_G1_MAIN_W, RV32_SECP_K1_MAIN_W};
+    for (int chip : {RV32_CHIP_FP_OP, RV32_CHIP_FP2_OP, RV32_CHIP_BLS_G1, RV32_CHIP_SECP_K1}) {
+        auto &evs = by_chip[chip];
+        T.present[chip] = !evs.empty();
+        T.log_n[chip] = 0;
+        T.main[chip].clear();
+        if (evs.empty()) continue;
+        const uint32_t lg = ceil_log2(evs.size());
+        const size_t n = (size_t)1 << lg;
+        T.log_n[chip] = lg;
+        T.main[chip].assign((size_t)widths[chip] * n, 0);
+        for (size_t row = 0; row < evs.size(); row++) {
+            const BigOpEvent &e = *evs[row];
+            RowRef R{T.main[chip].data(), n, row};
+            BigOpInfo bi;
+            bigop_info(e.code, &bi);
+            uint32_t ptrs[2] = {e.a_ptr, e.b_ptr};
+            if (chip == RV32_CHIP_FP_OP) {
+                const int op = (int)(e.code - SYS_BLS12381_FP_ADD);
+                R.put(RV32_FP_OP_is_real, 1); R.put(op == 0 ? RV32_FP_OP_is_add : op == 1 ? RV32_FP_OP_is_sub : RV32_FP_OP_is_mul, 1);
+                R.put(RV32_FP_OP_clk, e.clk);
+                R.bytes(RV32_FP_OP_xp_0, &ptrs[0], 1); R.bytes(RV32_FP_OP_yp_0, &ptrs[1], 1);
+                R.bytes(RV32_FP_OP_x_0, e.a, 12); R.bytes(RV32_FP_OP_y_0, e.b, 12); R.bytes(RV32_FP_OP_r_0, e.r, 12);
+                for (int k = 0; k < 12; k++) {
+                    mem_meta(R, RV32_FP_OP_my_sh_0, k, e.b_sh[k], e.b_ts[k], shard, e.clk + 2);
+                    mem_meta(R, RV32_FP_OP_mx_sh_0, k, e.a_sh[k], e.a_ts[k], shard, e.clk + 3);
+                }
+                if (!fill_lt(R, RV32_FP_OP_rlt_f_0, RV32_FP_OP_rlt_d_0, RV32_FP_OP_r_0, 48, rels_rv32::fp_op_0_mod)) { if (err) *err = "fp_op: result not reduced"; return false; }
+                if (!finish_row<air_rv32::FpOp>(R, rels_rv32::fp_op, rels_rv32::fp_op_n, pubs, byte_mult, err)) return false;
+            } else if (chip == RV32_CHIP_FP2_OP) {
+                const int op = (int)(e.code - SYS_BLS12381_FP2_ADD);
+                R.put(RV32_FP2_OP_is_real, 1); R.put(op == 0 ? RV32_FP2_OP_is_add : op == 1 ? RV32_FP2_OP_is_sub : RV32_FP2_OP_is_mul, 1);
+                R.put(RV32_FP2_OP_clk, e.clk);
+                R.bytes(RV32_FP2_OP_xp_0, &ptrs[0], 1); R.bytes(RV32_FP2_OP_yp_0, &ptrs[1], 1);
+                R.bytes(RV32_FP2_OP_x0_0, e.a, 12); R.bytes(RV32_FP2_OP_x1_0, e.a + 12, 12);
+                R.bytes(RV32_FP2_OP_y0_0, e.b, 12); R.bytes(RV32_FP2_OP_y1_0, e.b + 12, 12);
+                R.bytes(RV32_FP2_OP_r0_0, e.r, 12); R.bytes(RV32_FP2_OP_r1_0, e.r + 12, 12);
+                for (int k = 0; k < 24; k++) {
+                    mem_meta(R, RV32_FP2_OP_my_sh_0, k, e.b_sh[k], e.b_ts[k], shard, e.clk + 2);
+                    mem_meta(R, RV32_FP2_OP_mx_sh_0, k, e.a_sh[k], e.a_ts[k], shard, e.clk + 3);
+                }
+                if (!fill_lt(R, RV32_FP2_OP_r0lt_f_0, RV32_FP2_OP_r0lt_d_0, RV32_FP2_OP_r0_0, 48, rels_rv32::fp2_op_0_mod) ||
+                    !fill_lt(R, RV32_FP2_OP_r1lt_f_0, RV32_FP2_OP_r1lt_d_0, RV32_FP2_OP_r1_0, 48, rels_rv32::fp2_op_0_mod)) { if (err) *err = "fp2_op: result not reduced"; return false; }
+                if (!finish_row<air_rv32::Fp2Op>(R, rels_rv32::fp2_op, rels_rv32::fp2_op_n, pubs, byte_mult, err)) return false;
+            } else {
+                const bool is_bls = chip == RV32_CHIP_BLS_G1;
+                const WCols C = is_bls ? DVT_WCOLS(RV32_BLS_G1_) : DVT_WCOLS(RV32_SECP_K1_);
+                const int L = is_bls ? 48 : 32, W = L / 4;     // bytes / words per coordinate
+                const uint8_t *mod = is_bls ? rels_rv32::bls_g1_0_mod : rels_rv32::secp_k1_0_mod;
+                const bool add = bi.words_b != 0;
+                R.put(C.is_real, 1); R.put(add ? C.is_add : C.is_dbl, 1); R.put(C.clk, e.clk);
+                R.bytes(C.pp, &ptrs[0], 1); R.bytes(C.qp, &ptrs[1], 1);
+                R.bytes(C.x1, e.a, W); R.bytes(C.y1, e.a + W, W);
+                if (add) { R.bytes(C.x2, e.b, W); R.bytes(C.y2, e.b + W, W); }
+                R.bytes(C.lam, e.lam, W); R.bytes(C.x3, e.r, W); R.bytes(C.y3, e.r + W, W);
+                for (int k = 0; k < 2 * W; k++) {
+                    if (add) mem_meta(R, C.mq_sh, k, e.b_sh[k], e.b_ts[k], shard, e.clk + 2);
+                    mem_meta(R, C.mp_sh, k, e.a_sh[k], e.a_ts[k], shard, e.clk + 3);
+                }
+                bool ok = fill_lt(R, C.x1lt_f, C.x1lt_d, C.x1, L, mod) && fill_lt(R, C.y1lt_f, C.y1lt_d, C.y1, L, mod) &&
+                          fill_lt(R, C.x3lt_f, C.x3lt_d, C.x3, L, mod) && fill_lt(R, C.y3lt_f, C.y3lt_d, C.y3, L, mod);
+                if (add) ok = ok && fill_lt(R, C.x2lt_f, C.x2lt_d, C.x2, L, mod) && fill_lt(R, C.y2lt_f, C.y2lt_d, C.y2, L, mod) && fill_differ(R, C.xne_z, C.x1, C.x2, L);
+                if (!ok) { if (err) *err = "curve precompile row: a coordinate is not reduced or the abscissae are equal"; return false; }
+                if (is_bls ? !finish_row<air_rv32::BlsG1>(R, rels_rv32::bls_g1, rels_rv32::bls_g1_n, pubs, byte_mult, err)
+                           : !finish_row<air_rv32::SecpK1>(R, rels_rv32::secp_k1, rels_rv32::secp_k1_n, pubs, byte_mult, err)) return false;
+            }
+        }
+    }
+    return true;
+}
+
+}  // namespace rv32
+}  // namespace dvt
+#endif  // host pass

@@ -258,6 +258,7 @@ void Vm::run_shard(bool trace, ShardOut *out, uint64_t max_total_cycles) {
         out->alu.clear();
         out->sha_ext.clear();
         out->sha_cmp.clear();
+        out->big.clear();
         run<true>(out, budget);
         out->next_pc = pc;   // HALT_PC after HALT
     } else {
@@ -504,7 +505,44 @@ L_ECALL: {
         }
         break;
     }
-    default: why = "unknown syscall"; goto trapped;
+    default: {
+        // field / curve precompiles: a0 = operand replaced by the result, a1 = second operand (0 for DOUBLE)
+        BigOpInfo bi;
+        if (!bigop_info(b, &bi)) { why = "unknown syscall"; goto trapped; }
+        if (c % 4 || c < 32 || (uint64_t)c + 4 * bi.words_a > ADDR_LIMIT) { why = "precompile operand pointer misaligned or out of range"; goto trapped; }
+        if (bi.words_b ? (a1 % 4 || a1 < 32 || (uint64_t)a1 + 4 * bi.words_b > ADDR_LIMIT) : a1 != 0) {
+            why = bi.words_b ? "precompile operand pointer misaligned or out of range" : "DOUBLE precompile with a1 != 0"; goto trapped;
+        }
+        BigOpEvent lev, *ev = &lev;
+        auto touch = [&](uint32_t ad) -> Cell & {
+            Cell &cell = at(ad);
+            if (!(cell.flags & (FL_TOUCHED | FL_IMG))) { cell.flags |= FL_TOUCHED; if (collect_output) first_touch.emplace_back(ad, cell.val); }
+            return cell;
+        };
+        // values first (nothing is stamped if the call traps), then the accesses: b at clk + 2, a at clk + 3
+        for (int k = 0; k < bi.words_b; k++) { const Cell *cl = peek(a1 + 4 * k); lev.b[k] = cl ? cl->val : 0; }
+        for (int k = 0; k < bi.words_a; k++) { const Cell *cl = peek(c + 4 * k); lev.a[k] = cl ? cl->val : 0; }
+        why = bigop_compute(b, lev.a, lev.b, lev.r, lev.lam);
+        if (why) goto trapped;
+        {
+            Cell &r11 = regs[REG_A1];
+            if (TRACE) { rec.m_prev = r11.val; rec.m_ts = r11.ts(); shm = r11.sh(); }
+            r11.tsh = sh64 | (clk + 2);
+        }
+        if (TRACE) { out->big.emplace_back(lev); ev = &out->big.back(); ev->code = b; ev->clk = clk; ev->a_ptr = c; ev->b_ptr = a1; }
+        for (int k = 0; k < bi.words_b; k++) {
+            Cell &cell = touch(a1 + 4 * k);
+            if (TRACE) { ev->b_ts[k] = cell.ts(); ev->b_sh[k] = (uint16_t)cell.sh(); }
+            cell.tsh = sh64 | (clk + 2);
+        }
+        for (int k = 0; k < bi.words_a; k++) {
+            Cell &cell = touch(c + 4 * k);
+            if (TRACE) { ev->a_ts[k] = cell.ts(); ev->a_sh[k] = (uint16_t)cell.sh(); }
+            cell.val = lev.r[k];
+            cell.tsh = sh64 | (clk + 3);
+        }
+        break;
+    }
     }
     PORT_A(a);
     if (halted) {
@@ -591,6 +629,7 @@ void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin
             S.alu = out.alu;
             S.sha_ext = out.sha_ext;
             S.sha_cmp = out.sha_cmp;
+            S.big = out.big;
         }
         if (vm.halted || !vm.error.empty()) break;
         if (!vm.next_shard()) break;
@@ -682,7 +721,8 @@ std::vector<uint32_t> program_row_map(const Program &prog) {
 }
 
 bool build_aux_host(const ShardMeta &S, const std::vector<AluEvent> &alu, const std::vector<ShaExtEvent> &sha_ext,
-                    const std::vector<ShaCmpEvent> &sha_cmp, const std::vector<MemInitRow> *mem_rows, int exit_code, const HostPrep &prep, HostTraces *out, std::string *err) {
+                    const std::vector<ShaCmpEvent> &sha_cmp, const std::vector<BigOpEvent> &big, const std::vector<MemInitRow> *mem_rows, int exit_code,
+                    const HostPrep &prep, HostTraces *out, std::string *err) {
     HostTraces &T = *out;
     if (S.n_recs == 0) { if (err) *err = "no cycles to prove"; return false; }
     const bool last = mem_rows != nullptr;
@@ -718,7 +758,7 @@ bool build_aux_host(const ShardMeta &S, const std::vector<AluEvent> &alu, const 
                 sink.byte(B_RANGE - 1, (((w >> 16) & 0xff) << 8) | (w >> 24));
             }
             sink.byte(B_LTU - 1, ((m.addr >> 24) << 8) | ((ADDR_LIMIT >> 24) + 1));   // (+ 1: the registers sit at REG_BASE)
-            sink.byte(B_LTU - 1, ((d >> 24) << 8) | (ADDR_LIMIT >> 24));
+            sink.byte(B_LTU - 1, ((d >> 24) << 8) | ((ADDR_LIMIT >> 24) + 1));
             if (!m.is_img) {
                 sink.byte(B_RANGE - 1, ((m.v & 0xff) << 8) | ((m.v >> 8) & 0xff));
                 sink.byte(B_RANGE - 1, (((m.v >> 16) & 0xff) << 8) | (m.v >> 24));
@@ -992,6 +1032,8 @@ bool build_aux_host(const ShardMeta &S, const std::vector<AluEvent> &alu, const 
             }
         }
     }
+    // field / curve precompile chips: one row per call
+    if (!build_bigop_traces(big, S.index, &T, byte_mult.data(), err)) return false;
     const uint32_t lp = prep.log_n[RV32_CHIP_PROGRAM];
     T.log_n[RV32_CHIP_PROGRAM] = lp;
     T.main[RV32_CHIP_PROGRAM].assign((size_t)1 << lp, 0);
@@ -1009,7 +1051,7 @@ bool build_traces_host(const Program &prog, const ExecResult &res, size_t shard_
     if (res.unsupported) { if (err) *err = "unsupported " + res.unsupported_what; return false; }
     const ShardRec &S = res.shards[shard_pos];
     const bool last = shard_pos + 1 == res.shards.size();
-    if (!build_aux_host(ShardMeta{S.index, S.start_pc, S.next_pc, S.recs.size()}, S.alu, S.sha_ext, S.sha_cmp, last ? &res.mem_rows : nullptr, res.exit_code, prep, out, err)) return false;
+    if (!build_aux_host(ShardMeta{S.index, S.start_pc, S.next_pc, S.recs.size()}, S.alu, S.sha_ext, S.sha_cmp, S.big, last ? &res.mem_rows : nullptr, res.exit_code, prep, out, err)) return false;
     const size_t nc = (size_t)1 << T.log_n[RV32_CHIP_CPU];
     T.main[RV32_CHIP_CPU].assign((size_t)RV32_CPU_MAIN_W * nc, 0);
     std::vector<uint32_t> prog_idx_mult(prog.instrs.size(), 0);

@@ -71,6 +71,10 @@ struct ConstraintFolder {
         if constexpr (sizeof(T) == sizeof(Fp)) return Fp::raw(monty);
         else return Fp4::from_base(Fp::raw(monty));
     }
+    DVT_HD static T KI(uint32_t canonical) {   // a constant computed at run time (looped interactions of the generated code)
+        if constexpr (sizeof(T) == sizeof(Fp)) return Fp::from_canonical(canonical);
+        else return Fp4::from_base(Fp::from_canonical(canonical));
+    }
     DVT_HD T main(int c, int r) const { return ax.main(c, r); }
     DVT_HD T prep(int c, int r) const { return ax.prep(c, r); }
     DVT_HD T pub(int k) const { return ax.pub(k); }
@@ -242,6 +246,7 @@ struct PermRowCtx {
     Fp4 batch, total;
     __device__ PermRowCtx(const PermArgs &args, size_t r) : a(args), n((size_t)1 << args.log_n), row(r), batch(Fp4::zero()), total(Fp4::zero()) {}
     __device__ static T K(uint32_t m) { return Fp::raw(m); }
+    __device__ static T KI(uint32_t canonical) { return Fp::from_canonical(canonical); }
     __device__ T main(int c, int r) const { return Fp::raw(a.main[(size_t)c * n + ((row + r) & (n - 1))]); }
     __device__ T prep(int c, int r) const { return Fp::raw(a.prep[(size_t)c * n + ((row + r) & (n - 1))]); }
     __device__ T pub(int k) const { return Fp::raw(a.pub[k]); }

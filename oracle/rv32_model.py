@@ -19,7 +19,7 @@ import numpy as np
 P = 2013265921
 M32 = 0xFFFFFFFF
 ADDR_LIMIT = 0x38000000
-REG_BASE = ADDR_LIMIT        # the registers are words REG_BASE + 0..31 of the memory argument (above every guest address)
+REG_BASE = ADDR_LIMIT + (1 << 23)   # the registers are words REG_BASE + 0..31 of the memory argument (above every guest address)
 HALT_PC = 1 << 30            # next_pc of a HALT row: no other row can produce it
 BAD_PC = 1                   # program-table target of a JAL / branch whose static target lies outside the text
 B_AND, B_OR, B_XOR, B_LTU, B_MSB, B_RANGE, B_U16, B_ADDR = 1, 2, 3, 4, 5, 6, 7, 8
@@ -31,6 +31,56 @@ SHA_K = [
     0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
     0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2]
 ALU_CODES = dict(sll=1, srl=2, sra=3, mulh=4, mulhsu=5, div=6, divu=7, rem=8, remu=9)
+# field / curve precompiles (SP1's syscall numbers as best recalled [EXTERNAL, unverified]): code -> (chip, operation,
+# words of the operand at a0, words of the operand at a1)
+BLS_P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+SECP_P = (1 << 256) - (1 << 32) - 977
+BIG_OPS = {0x00010120: ("fp_op", "add", 12, 12), 0x00010121: ("fp_op", "sub", 12, 12), 0x00010122: ("fp_op", "mul", 12, 12),
+           0x00010123: ("fp2_op", "add", 24, 24), 0x00010124: ("fp2_op", "sub", 24, 24), 0x00010125: ("fp2_op", "mul", 24, 24),
+           0x0001011E: ("bls_g1", "add", 24, 24), 0x0000011F: ("bls_g1", "dbl", 24, 0),
+           0x0001010A: ("secp_k1", "add", 16, 16), 0x0000010B: ("secp_k1", "dbl", 16, 0)}
+
+
+def words_to_int(ws):
+    return sum(w << (32 * i) for i, w in enumerate(ws))
+
+
+def int_to_words(v, n):
+    return [(v >> (32 * i)) & M32 for i in range(n)]
+
+
+def big_op(chip, op, a, b):
+    """-> (result words, slope or None) of one call, or raises Trap: the guest machine's semantics of the precompiles.
+    Field operands may be any 384-bit numbers (the result is reduced); curve coordinates must be reduced."""
+    if chip in ("fp_op", "fp2_op"):
+        f = {"add": lambda x, y: (x + y) % BLS_P, "sub": lambda x, y: (x - y) % BLS_P, "mul": lambda x, y: x * y % BLS_P}[op]
+        if chip == "fp_op":
+            return int_to_words(f(words_to_int(a), words_to_int(b)), 12), None
+        x0, x1, y0, y1 = words_to_int(a[:12]), words_to_int(a[12:]), words_to_int(b[:12]), words_to_int(b[12:])
+        if op == "mul":
+            r0, r1 = (x0 * y0 - x1 * y1) % BLS_P, (x0 * y1 + x1 * y0) % BLS_P
+        else:
+            r0, r1 = f(x0, y0), f(x1, y1)
+        return int_to_words(r0, 12) + int_to_words(r1, 12), None
+    p, w = (BLS_P, 12) if chip == "bls_g1" else (SECP_P, 8)
+    x1, y1 = words_to_int(a[:w]), words_to_int(a[w:])
+    if x1 >= p or y1 >= p:
+        raise Trap("curve precompile: coordinate of p not reduced")
+    if op == "add":
+        x2, y2 = words_to_int(b[:w]), words_to_int(b[w:])
+        if x2 >= p or y2 >= p:
+            raise Trap("curve precompile: coordinate of q not reduced")
+        if x1 == x2:
+            raise Trap("ADD precompile with equal abscissae (p = q or p = -q: the guest must handle those)")
+        lam = (y2 - y1) * pow(x2 - x1, -1, p) % p
+    else:
+        if y1 == 0:
+            raise Trap("DOUBLE precompile of a point with y = 0")
+        x2 = x1
+        lam = 3 * x1 * x1 * pow(2 * y1, -1, p) % p
+    x3 = (lam * lam - x1 - x2) % p
+    y3 = (lam * (x1 - x3) - y1) % p
+    return int_to_words(x3, w) + int_to_words(y3, w), lam
 
 
 def sx(v, bits=32):
@@ -211,7 +261,7 @@ class Run:
     def _run(self, max_cycles):
         pc, shard, i_in = self.entry, 1, 0
         size = 1 << self.log_shard
-        cur = dict(index=1, start_pc=pc, rows=[], alu=[], sha_ext=[], sha_cmp=[])
+        cur = dict(index=1, start_pc=pc, rows=[], alu=[], sha_ext=[], sha_cmp=[], big=[])
         while True:
             if self.cycles >= max_cycles:
                 raise Trap("cycle limit reached before HALT")
@@ -219,7 +269,7 @@ class Run:
                 cur["next_pc"] = pc
                 self.shards.append(cur)
                 shard, i_in = shard + 1, 0
-                cur = dict(index=shard, start_pc=pc, rows=[], alu=[], sha_ext=[], sha_cmp=[])
+                cur = dict(index=shard, start_pc=pc, rows=[], alu=[], sha_ext=[], sha_cmp=[], big=[])
             ins = self.text.get(pc)
             if ins is None:
                 raise Trap("pc outside text at pc 0x%x" % pc)
@@ -405,6 +455,33 @@ class Run:
                         if (c + j) in self.image_mem or (c + j) in self.mem_t:
                             raise Trap("HINT_READ into the program image or into memory that was already accessed at pc 0x%x" % pc)
                         self.mem[c + j] = struct.unpack_from("<I", padded, j)[0]
+                elif b in BIG_OPS:
+                    # field / curve precompiles: a0 -> operand replaced by the result (read and written at clk + 3),
+                    # a1 -> second operand (read at clk + 2; 0 for DOUBLE)
+                    chip_, op_, wa, wb = BIG_OPS[b]
+                    if c % 4 or c < 32 or c + 4 * wa > ADDR_LIMIT or (wb and (a1 % 4 or a1 < 32 or a1 + 4 * wb > ADDR_LIMIT)):
+                        raise Trap("precompile operand pointer misaligned or out of range at pc 0x%x" % pc)
+                    if not wb and a1 != 0:
+                        raise Trap("DOUBLE precompile with a1 != 0 at pc 0x%x" % pc)
+                    va = [self.mem.get(c + 4 * j, 0) for j in range(wa)]
+                    vb = [self.mem.get(a1 + 4 * j, 0) for j in range(wb)]
+                    try:
+                        res, lam = big_op(chip_, op_, va, vb)
+                    except Trap as e:
+                        raise Trap("%s at pc 0x%x" % (e, pc))
+                    row.mem = self._touch_reg(11, (shard, clk + 2))
+                    row.maddr, row.m_prev, row.m_val = 11, a1, a1
+                    bprev, aprev = [], []
+                    for j in range(wb):
+                        self._mem_word(a1 + 4 * j)
+                        bprev.append(self.mem_t.get(a1 + 4 * j, (0, 0)))
+                        self.mem_t[a1 + 4 * j] = (shard, clk + 2)
+                    for j in range(wa):
+                        self._mem_word(c + 4 * j)
+                        aprev.append(self.mem_t.get(c + 4 * j, (0, 0)))
+                        self.mem[c + 4 * j] = res[j]
+                        self.mem_t[c + 4 * j] = (shard, clk + 3)
+                    cur["big"].append(dict(chip=chip_, op=op_, clk=clk, a_ptr=c, b_ptr=a1, a=va, b=vb, r=res, lam=lam, aprev=aprev, bprev=bprev))
                 else:
                     raise Trap("unknown syscall at pc 0x%x" % pc)
             else:
@@ -757,7 +834,7 @@ def traces(run: Run, pos: int):
             d = addr - prev - 1 if prev is not None else 0
             putv("ab", byts(addr)); putv("v", byts(v)); putv("f", byts(f)); putv("d", byts(d))
             put("fts", t[1]); put("fsh", t[0]); put("is_img", is_img); put("is_real", 1)
-            for w, top in ((addr, (ADDR_LIMIT >> 24) + 1), (d, ADDR_LIMIT >> 24)):      # (+ 1: the registers at REG_BASE)
+            for w, top in ((addr, (ADDR_LIMIT >> 24) + 1), (d, (ADDR_LIMIT >> 24) + 1)):      # (+ 1: the registers at REG_BASE)
                 lk.add(B_RANGE, byts(w)[0], byts(w)[1]); lk.add(B_RANGE, byts(w)[2], byts(w)[3]); lk.add(B_LTU, byts(w)[3], top)
             if not is_img:
                 lk.add(B_RANGE, byts(v)[0], byts(v)[1]); lk.add(B_RANGE, byts(v)[2], byts(v)[3])
@@ -859,6 +936,174 @@ def traces(run: Run, pos: int):
                     lk.add(B_ADDR, byts(ev["w_ptr"])[0], byts(ev["w_ptr"])[3]); lk.add(B_ADDR, byts(ev["h_ptr"])[0], byts(ev["h_ptr"])[3])
                 v = [nxt_a, v[0], v[1], v[2], nxt_e, v[4], v[5], v[6]]
         out["sha_compress"] = mat
+
+    # ---- field / curve precompile chips: one row per call.  The big-integer identities are restated here limb by limb
+    # (convolutions of byte vectors); only the carry OFFSETS (constants the AIR picked) are read from its description.
+    def bytes_of(v, n):
+        return [(v >> (8 * i)) & 0xFF for i in range(n)]
+
+    def conv(x, y):
+        out = [0] * (len(x) + len(y) - 1)
+        for i, xi in enumerate(x):
+            if xi:
+                for j, yj in enumerate(y):
+                    out[i + j] += xi * yj
+        return out
+
+    def lin(K, *terms):
+        """sum of coef * limb vector (padded to K coefficients)"""
+        out = [0] * K
+        for coef, v in terms:
+            for i, x in enumerate(v):
+                out[i] += coef * x
+        return out
+
+    def carry_cells(put, name, rel, coefs):
+        """carries W_k = (c_k + W_(k-1)) / 256 of an identity whose coefficients are `coefs`; cell = W_k + offset, low 16
+        bits and (when the AIR gave the identity a top-bit column) the bit above"""
+        W, wide = 0, rel.w_top is not None
+        assert len(coefs) == rel.K
+        for k in range(rel.K - 1):
+            t = coefs[k] + W
+            assert t % 256 == 0
+            W = t // 256
+            cell = W + rel.w_off[k]
+            assert 0 <= cell < (1 << 17 if wide else 1 << 16)
+            put(f"{name}_w[{k}]", cell & 0xFFFF)
+            if wide:
+                put(f"{name}_wb[{k}]", cell >> 16)
+            lk.add(B_U16, cell & 0xFFFF)
+        assert coefs[-1] + W == 0
+
+    def range_pairs(vals):
+        for i in range(0, len(vals) - 1, 2):
+            lk.add(B_RANGE, vals[i], vals[i + 1])
+        if len(vals) % 2:
+            lk.add(B_RANGE, vals[-1], 0)
+
+    def lt_cells(put, putv, name, v, p, L):
+        """v < p on 3-byte groups: flag of the most significant group that differs, p_g - v_g - 1 there"""
+        vb, pb = bytes_of(v, L), bytes_of(p, L)
+        G = (L + 2) // 3
+        grp = lambda bs, g: sum(x << (8 * t) for t, x in enumerate(bs[3 * g:3 * g + 3]))
+        g = next(g for g in reversed(range(G)) if grp(vb, g) != grp(pb, g))
+        assert grp(vb, g) < grp(pb, g)
+        d = grp(pb, g) - grp(vb, g) - 1
+        put(f"{name}_f[{g}]", 1)
+        putv(f"{name}_d", bytes_of(d, 3))
+        lk.add(B_RANGE, d & 0xFF, (d >> 8) & 0xFF); lk.add(B_RANGE, d >> 16, 0)
+
+    def mem_cells(put, name, prevs, ts):
+        his = []
+        for k_, prev in enumerate(prevs):
+            same, lo, h = gap(prev, ts)
+            put(f"{name}_sh[{k_}]", prev[0]); put(f"{name}_ts[{k_}]", prev[1]); put(f"{name}_same[{k_}]", same)
+            put(f"{name}_lo[{k_}]", lo); put(f"{name}_hi[{k_}]", h)
+            lk.add(B_U16, lo)
+            his.append(h)
+        range_pairs(his)
+
+    for cname_ in ("fp_op", "fp2_op", "bls_g1", "secp_k1"):
+        evs = [e for e in sh["big"] if e["chip"] == cname_]
+        if not evs:
+            continue
+        cid, chip = chips[cname_]
+        rels = {r.name: r for r in chip.poly_rels}
+        mat = np.zeros((chip.main_width, 1 << log2ceil(len(evs))), np.int64)
+        for r_, ev in enumerate(evs):
+            put, putv = _col_setter(chip, mat, r_)
+            op = ev["op"]
+            put("is_real", 1); put("is_" + op, 1); put("clk", ev["clk"])
+            if cname_ in ("fp_op", "fp2_op"):
+                L, p_ = 48, BLS_P
+                Pl = bytes_of(p_, L)
+                putv("xp", byts(ev["a_ptr"])); putv("yp", byts(ev["b_ptr"]))
+                lk.add(B_ADDR, byts(ev["a_ptr"])[0], byts(ev["a_ptr"])[3]); lk.add(B_ADDR, byts(ev["b_ptr"])[0], byts(ev["b_ptr"])[3])
+                mem_cells(put, "my", ev["bprev"], ev["clk"] + 2)
+                mem_cells(put, "mx", ev["aprev"], ev["clk"] + 3)
+                parts = 1 if cname_ == "fp_op" else 2
+                xs = [words_to_int(ev["a"][12 * i:12 * i + 12]) for i in range(parts)]
+                ys = [words_to_int(ev["b"][12 * i:12 * i + 12]) for i in range(parts)]
+                rs = [words_to_int(ev["r"][12 * i:12 * i + 12]) for i in range(parts)]
+                sfx = [""] if parts == 1 else ["0", "1"]
+                for i in range(parts):
+                    putv("x" + sfx[i], bytes_of(xs[i], L)); putv("y" + sfx[i], bytes_of(ys[i], L)); putv("r" + sfx[i], bytes_of(rs[i], L))
+                    range_pairs(bytes_of(rs[i], L))
+                for i in range(parts):
+                    xb, yb, rb = bytes_of(xs[i], L), bytes_of(ys[i], L), bytes_of(rs[i], L)
+                    K = 2 * L
+                    if op == "mul" and parts == 1:
+                        V, co = xs[0] * ys[0] - rs[0], lin(K, (1, conv(xb, yb)), (-1, rb))
+                    elif op == "mul" and i == 0:     # x0 y0 - x1 y1 + 2^388 p - r0
+                        off = bytes_of(1 << 388, L + 1)
+                        V = xs[0] * ys[0] - xs[1] * ys[1] + (p_ << 388) - rs[0]
+                        co = lin(K, (1, conv(bytes_of(xs[0], L), bytes_of(ys[0], L))), (-1, conv(bytes_of(xs[1], L), bytes_of(ys[1], L))), (1, conv(off, Pl)), (-1, rb))
+                    elif op == "mul":                # x0 y1 + x1 y0 - r1
+                        V = xs[0] * ys[1] + xs[1] * ys[0] - rs[1]
+                        co = lin(K, (1, conv(bytes_of(xs[0], L), bytes_of(ys[1], L))), (1, conv(bytes_of(xs[1], L), bytes_of(ys[0], L))), (-1, rb))
+                    elif op == "add":
+                        V, co = xs[i] + ys[i] - rs[i], lin(K, (1, xb), (1, yb), (-1, rb))
+                    else:                            # x - y + 10 p - r
+                        V, co = xs[i] - ys[i] + 10 * p_ - rs[i], lin(K, (1, xb), (-1, yb), (10, Pl), (-1, rb))
+                    assert V % p_ == 0 and V >= 0
+                    qv = bytes_of(V // p_, L + 1)
+                    putv("q" + sfx[i], qv)
+                    range_pairs(qv)
+                    co = [a_ - b_ for a_, b_ in zip(co, lin(K, (1, conv(qv, Pl))))]
+                    lt_cells(put, putv, ("r" + sfx[i] + "lt"), rs[i], p_, L)
+                    carry_cells(put, "rel" + sfx[i], rels["rel" + sfx[i]], co)
+            else:
+                L, p_ = (48, BLS_P) if cname_ == "bls_g1" else (32, SECP_P)
+                Wn, K, M_ = L // 4, 2 * L, 1 << (8 * L)
+                Pl = bytes_of(p_, L)
+                add = op == "add"
+                putv("pp", byts(ev["a_ptr"])); putv("qp", byts(ev["b_ptr"]))
+                lk.add(B_ADDR, byts(ev["a_ptr"])[0], byts(ev["a_ptr"])[3])
+                if add:
+                    lk.add(B_ADDR, byts(ev["b_ptr"])[0], byts(ev["b_ptr"])[3])
+                    mem_cells(put, "mq", ev["bprev"], ev["clk"] + 2)
+                mem_cells(put, "mp", ev["aprev"], ev["clk"] + 3)
+                x1, y1 = words_to_int(ev["a"][:Wn]), words_to_int(ev["a"][Wn:])
+                x2, y2 = (words_to_int(ev["b"][:Wn]), words_to_int(ev["b"][Wn:])) if add else (0, 0)
+                x3, y3, lam = words_to_int(ev["r"][:Wn]), words_to_int(ev["r"][Wn:]), ev["lam"]
+                B = lambda v: bytes_of(v, L)
+                for nm_, v in (("x1", x1), ("y1", y1), ("x2", x2), ("y2", y2), ("lam", lam), ("x3", x3), ("y3", y3)):
+                    putv(nm_, B(v))
+                for v in (lam, x3, y3):
+                    range_pairs(B(v))
+                # slope:  ADD  lam (x2 - x1) - (y2 - y1) + 4 M p,   DOUBLE  2 lam y1 - 3 x1^2 + 4 M p
+                offp = conv(bytes_of(4 * M_, L + 1), Pl)
+                if add:
+                    V1 = lam * (x2 - x1) - (y2 - y1) + 4 * M_ * p_
+                    c1 = lin(K, (1, conv(B(lam), B(x2))), (-1, conv(B(lam), B(x1))), (-1, B(y2)), (1, B(y1)), (1, offp))
+                else:
+                    V1 = 2 * lam * y1 - 3 * x1 * x1 + 4 * M_ * p_
+                    c1 = lin(K, (2, conv(B(lam), B(y1))), (-3, conv(B(x1), B(x1))), (1, offp))
+                xs_ = x2 if add else x1
+                V2 = lam * lam - x1 - xs_ - x3 + 4 * p_
+                c2 = lin(K, (1, conv(B(lam), B(lam))), (-1, B(x1)), (-1, B(xs_)), (-1, B(x3)), (4, Pl))
+                V3 = lam * (x1 - x3) - y1 - y3 + 2 * M_ * p_
+                c3 = lin(K, (1, conv(B(lam), B(x1))), (-1, conv(B(lam), B(x3))), (-1, B(y1)), (-1, B(y3)), (1, conv(bytes_of(2 * M_, L + 1), Pl)))
+                qvs = []
+                for i, (V, co) in enumerate(((V1, c1), (V2, c2), (V3, c3)), start=1):
+                    assert V % p_ == 0 and V >= 0
+                    qv = bytes_of(V // p_, L + 1)
+                    putv(f"q{i}", qv)
+                    qvs.append((qv, co))
+                for qv, _ in qvs:
+                    range_pairs(qv)
+                checks = [("x1lt", x1), ("y1lt", y1)] + ([("x2lt", x2), ("y2lt", y2)] if add else []) + [("x3lt", x3), ("y3lt", y3)]
+                for nm_, v in checks:
+                    lt_cells(put, putv, nm_, v, p_, L)
+                if add:      # x1 != x2: the inverse of one differing 3-byte group
+                    G = (L + 2) // 3
+                    grp = lambda v, g: (v >> (24 * g)) & 0xFFFFFF
+                    g = next(g for g in range(G) if grp(x1, g) != grp(x2, g))
+                    put(f"xne_z[{g}]", inv(grp(x1, g) - grp(x2, g)))
+                for i, (qv, co) in enumerate(qvs, start=1):
+                    co = [a_ - b_ for a_, b_ in zip(co, lin(K, (1, conv(qv, Pl))))]
+                    carry_cells(put, f"rel{i}", rels[f"rel{i}"], co)
+        out[cname_] = mat
 
     # ---- preprocessed chips and their multiplicity columns
     cidp, chipp = chips["program"]

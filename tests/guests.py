@@ -713,7 +713,8 @@ DKG_A = [(0x9E3779B9 * (i + 1)) & M32 for i in range(DKG_L)]
 DKG_B = [(0x85EBCA6B * (i + 3) + 7) & M32 for i in range(DKG_L)]
 DKG_A2 = [(0xC2B2AE35 * (i + 5) + 1) & M32 for i in range(DKG_L2)]
 DKG_B2 = [(0x27D4EB2F * (i + 2) + 3) & M32 for i in range(DKG_L2)]
-PV_MAX_WORDS = (192 + 32 * 255 + 4 * (2 * DKG_L + 2) + 4 * (2 * DKG_L2 + 2) + 128) // 4
+PV_MAX_WORDS = (192 + 32 * 255 + 4 * (2 * DKG_L + 2) + 4 * (2 * DKG_L2 + 2) + 48 + 128) // 4
+DKG_NC = 4      # curve_precompiles mode: the per-key point operations cycle through [2] G, [3] G, [4] G, [5] G
 
 
 def _emit_mulacc(a):
@@ -809,16 +810,33 @@ def chacha20_block_py(state):
     return [(x[i] + state[i]) & M32 for i in range(16)]
 
 
-def dkg_like(kind="finalization", sig_iters=2, pt_iters=1, pair_iters=1, sha_precompiles=False):
+def dkg_like(kind="finalization", sig_iters=2, pt_iters=1, pair_iters=1, sha_precompiles=False, curve_precompiles=False):
     """The n-participant DKG-shaped guest (see the block comment above).  kind = "finalization" | "encshare".  The ELF
     depends only on the iteration constants; n and k come from the stdin buffer at run time.  Returns the ELF;
-    dkg_like_expected() is the same computation in Python."""
+    dkg_like_expected() is the same computation in Python.
+    curve_precompiles=True: the k point operations of every participant are REAL BLS12-381 G1 arithmetic through SP1's
+    BLS12381_ADD / _DOUBLE precompiles (what the reference's guests do through the patched bls12_381 crate, reference
+    crates/dkg/Cargo.toml:25): Y := [i + 1] Y + C_j for j < k, the Horner step of reference crates/dkg/src/dkg_math.rs:160-174
+    with the participant's id as the scalar; the compressed Y is appended to the public values.  (The signature check
+    stays the multiply-accumulate stand-in: pairings need the Fp12 tower in guest code.)"""
     import hashlib  # noqa: F401  (the model below uses it; imported here to fail early if missing)
 
     assert kind in ("finalization", "encshare")
     L, L2 = DKG_L, DKG_L2
     a = Asm()
     a.sha_precompiles = sha_precompiles
+    lib = None
+    if curve_precompiles:
+        from tests import guests_bls
+        from tools import bls12_381 as bls
+
+        lib = guests_bls.G1Lib(a)
+        pw = lambda pt: guests_bls.words_of(pt[0], 12) + guests_bls.words_of(pt[1], 12) + [0]
+        g_y = a.dword("g1_y", pw(bls.G1))
+        g_tmp = a.dword("g1_tmp", [0] * 25)
+        g_c = a.dword("g1_c", [w for m in range(2, 2 + DKG_NC) for w in pw(bls.E1.mul(bls.G1, m))])
+        g_id = a.dword("g1_id", [0])
+        g_out = a.dword("g1_out", [0] * 12)
     pa, pb = a.dword("x", DKG_A), a.dword("y", DKG_B)
     pt = a.dword("t", [0] * (2 * L + 2))
     pa2, pb2 = a.dword("x2", DKG_A2), a.dword("y2", DKG_B2)
@@ -863,7 +881,11 @@ def dkg_like(kind="finalization", sig_iters=2, pt_iters=1, pair_iters=1, sha_pre
     _emit_mulacc(a)
     if kind == "encshare":
         _emit_chacha(a)
+    if lib:
+        lib.emit()
     a.label("main")
+    if lib:
+        a.li("sp", lib.stack)
     # ---- read the one stdin buffer
     a.li("t0", SYS_HINT_LEN)
     a.ecall()
@@ -965,7 +987,7 @@ def dkg_like(kind="finalization", sig_iters=2, pt_iters=1, pair_iters=1, sha_pre
     store_var("s10", V_PV)
     # signature check + k point operations: (SIG + k PT) x { t += x * y ; x = t mod 2^384 }
     load_var("t1", V_K)
-    a.li("t2", pt_iters)
+    a.li("t2", 0 if lib else pt_iters)
     a.mul("t1", "t1", "t2")
     a.li("t2", sig_iters)
     a.add("t1", "t1", "t2")
@@ -978,6 +1000,32 @@ def dkg_like(kind="finalization", sig_iters=2, pt_iters=1, pair_iters=1, sha_pre
     a.addi("t1", "t1", -1)
     store_var("t1", V_R)
     a.bne("t1", "zero", "big")
+    if lib:
+        # the k point operations of participant i on the curve: Y := [i + 1] Y + C_(j mod NC), j < k
+        load_var("t1", V_I)
+        a.addi("t1", "t1", 1)
+        store_var("t1", g_id)
+        a.li("t1", 0)
+        store_var("t1", V_R)
+        a.label("ptop")
+        a.li("a0", g_tmp); a.li("a1", g_y); a.li("a2", g_id); a.li("a3", 1)
+        a.call("scalar_mul")
+        load_var("t1", V_R)
+        a.andi("t1", "t1", DKG_NC - 1)
+        a.li("t2", 100)
+        a.mul("t1", "t1", "t2")
+        a.li("a1", g_c)
+        a.add("a1", "a1", "t1")
+        a.li("a0", g_tmp)
+        a.call("g1_add")
+        a.li("t4", g_y)
+        a.li("t5", g_tmp)
+        lib.copy_words("t4", "t5", 25)
+        load_var("t1", V_R)
+        a.addi("t1", "t1", 1)
+        store_var("t1", V_R)
+        load_var("t2", V_K)
+        a.bne("t1", "t2", "ptop")
     # the n^2 term: for every j: PAIR x { t2 += x2 * y2 ; x2 = t2 mod 2^128 } with y2[0] = digest word 0 ^ i, y2[1] = j
     a.li("s8", state)
     a.lw("t1", "s8", 0)
@@ -1013,6 +1061,16 @@ def dkg_like(kind="finalization", sig_iters=2, pt_iters=1, pair_iters=1, sha_pre
             a.lw("t1", "s8", 4 * w)
             a.sw("t1", "s10", 4 * w)
         a.addi("s10", "s10", 4 * nw)
+    if lib:
+        store_var("s10", V_PV)
+        a.li("a0", g_out); a.li("a1", g_y)
+        a.call("g1_compress")
+        load_var("s10", V_PV)
+        a.li("s8", g_out)
+        for w in range(12):
+            a.lw("t1", "s8", 4 * w)
+            a.sw("t1", "s10", 4 * w)
+        a.addi("s10", "s10", 48)
     a.li("s9", pvbuf)
     a.sub("s11", "s10", "s9")                    # T = public-value bytes
     a.li("a0", 3)
@@ -1054,7 +1112,7 @@ def dkg_like(kind="finalization", sig_iters=2, pt_iters=1, pair_iters=1, sha_pre
     return a.elf()
 
 
-def dkg_like_expected(stdin_buf: bytes, kind="finalization", sig_iters=2, pt_iters=1, pair_iters=1):
+def dkg_like_expected(stdin_buf: bytes, kind="finalization", sig_iters=2, pt_iters=1, pair_iters=1, curve_precompiles=False):
     """Python model of dkg_like: the public-value bytes the guest must commit for this input"""
     import hashlib
 
@@ -1075,6 +1133,10 @@ def dkg_like_expected(stdin_buf: bytes, kind="finalization", sig_iters=2, pt_ite
     x2, y2w = sum(w << (32 * i) for i, w in enumerate(DKG_A2)), list(DKG_B2)
     t = t2 = 0
     pv = b""
+    if curve_precompiles:
+        from tools import bls12_381 as bls
+
+        Y, Cs = bls.G1, [bls.E1.mul(bls.G1, m) for m in range(2, 2 + DKG_NC)]
     if kind == "encshare":
         key = hashlib.sha256(bytes(buf[8:72])).digest()
         kw = list(struct.unpack("<8I", key))
@@ -1091,9 +1153,12 @@ def dkg_like_expected(stdin_buf: bytes, kind="finalization", sig_iters=2, pt_ite
         h = struct.unpack(">8I", d)
         y ^= sum(w << (32 * j) for j, w in enumerate(h))
         pv += d
-        for _ in range(sig_iters + k * pt_iters):
+        for _ in range(sig_iters + (0 if curve_precompiles else k * pt_iters)):
             t += x * y
             x = t & ((1 << (32 * L)) - 1)
+        if curve_precompiles:
+            for j in range(k):
+                Y = bls.E1.add(bls.E1.mul(Y, i + 1), Cs[j % DKG_NC])
         y2w[0] = h[0] ^ i
         for j in range(n):
             y2w[1] = j
@@ -1103,4 +1168,146 @@ def dkg_like_expected(stdin_buf: bytes, kind="finalization", sig_iters=2, pt_ite
                 x2 = t2 & ((1 << (32 * L2)) - 1)
     assert t < 1 << (32 * (2 * L + 2)) and t2 < 1 << (32 * (2 * L2 + 2))
     pv += t.to_bytes(4 * (2 * L + 2), "little") + t2.to_bytes(4 * (2 * L2 + 2), "little")
+    if curve_precompiles:
+        pv += bls.g1_compress(Y)
     return pv
+
+
+# ------------------------------------------------------------------------------------------------ field / curve precompiles
+# SP1's syscall numbers as best recalled [EXTERNAL, unverified] (tools/airgen/rv32.py)
+SYS_SECP256K1_ADD, SYS_SECP256K1_DOUBLE = 0x0001010A, 0x0000010B
+SYS_BLS12381_ADD, SYS_BLS12381_DOUBLE = 0x0001011E, 0x0000011F
+SYS_BLS12381_FP_ADD, SYS_BLS12381_FP_SUB, SYS_BLS12381_FP_MUL = 0x00010120, 0x00010121, 0x00010122
+SYS_BLS12381_FP2_ADD, SYS_BLS12381_FP2_SUB, SYS_BLS12381_FP2_MUL = 0x00010123, 0x00010124, 0x00010125
+BLS_P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+SECP_P = (1 << 256) - (1 << 32) - 977
+SECP_G = (0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798, 0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8)
+BLS_G1 = (0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,
+          0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1)
+
+
+def words_of(v, n):
+    return [(v >> (32 * i)) & M32 for i in range(n)]
+
+
+def _syscall(a, code, a0, a1):
+    a.li("a0", a0)
+    a.li("a1", a1)
+    a.li("t0", code)
+    a.ecall()
+
+
+def ec_add(p, q, mod):
+    """affine addition on y^2 = x^3 + b (a = 0), p != +-q, no point at infinity: plain Python restatement"""
+    (x1, y1), (x2, y2) = p, q
+    lam = (y2 - y1) * pow(x2 - x1, -1, mod) % mod
+    x3 = (lam * lam - x1 - x2) % mod
+    return x3, (lam * (x1 - x3) - y1) % mod
+
+
+def ec_double(p, mod):
+    x1, y1 = p
+    lam = 3 * x1 * x1 * pow(2 * y1, -1, mod) % mod
+    x3 = (lam * lam - 2 * x1) % mod
+    return x3, (lam * (x1 - x3) - y1) % mod
+
+
+def field_ops(bad=None):
+    """BLS12-381 Fp and Fp2 add / sub / mul precompiles on reduced, unreduced and aliased operands.  Returns
+    (elf, expected result bytes): every result (12 or 24 words) goes to fd 1, their checksum() to the public values.
+    bad: "misaligned" / "low" / "high" pointer -> the call traps."""
+    p = BLS_P
+    top = (1 << 384) - 1
+    vals = [0, 1, p - 1, p, p + 5, top, 0x1234567 << 300 | 0xABCDEF, (p * 7) // 11, top - 12345, 2, (p + 1) // 2]
+    a = Asm()
+    cases = []     # (code, x words, y words or None for y = x (same pointer), expected words)
+    f = {0: lambda x, y: (x + y) % p, 1: lambda x, y: (x - y) % p, 2: lambda x, y: x * y % p}
+    k = 0
+    for op in (0, 1, 2):
+        for i in range(4):
+            x, y = vals[(k * 3 + 1) % len(vals)], vals[(k * 5 + 2) % len(vals)]
+            k += 1
+            cases.append((SYS_BLS12381_FP_ADD + op, words_of(x, 12), words_of(y, 12), words_of(f[op](x, y), 12)))
+        x = vals[(k + 5) % len(vals)]
+        cases.append((SYS_BLS12381_FP_ADD + op, words_of(x, 12), None, words_of(f[op](x, x), 12)))       # x op x through ONE pointer
+    for op in (0, 1, 2):
+        for i in range(3):
+            x0, x1, y0, y1 = (vals[(k * 7 + j) % len(vals)] for j in (1, 4, 6, 9))
+            k += 1
+            if op == 2:
+                r0, r1 = (x0 * y0 - x1 * y1) % p, (x0 * y1 + x1 * y0) % p
+            else:
+                r0, r1 = f[op](x0, y0), f[op](x1, y1)
+            cases.append((SYS_BLS12381_FP2_ADD + op, words_of(x0, 12) + words_of(x1, 12), words_of(y0, 12) + words_of(y1, 12), words_of(r0, 12) + words_of(r1, 12)))
+        x0, x1 = vals[(k + 2) % len(vals)], vals[(k + 7) % len(vals)]
+        r = ((x0 * x0 - x1 * x1) % p, 2 * x0 * x1 % p) if op == 2 else (f[op](x0, x0), f[op](x1, x1))
+        cases.append((SYS_BLS12381_FP2_ADD + op, words_of(x0, 12) + words_of(x1, 12), None, words_of(r[0], 12) + words_of(r[1], 12)))
+    exp = []
+    nres = sum(len(c[3]) for c in cases)
+    out = a.dword("out", [0] * (nres + 4))
+    at = out
+    for n_, (code, xw, yw, rw) in enumerate(cases):
+        # the operand that is replaced lives in the output area (so the result lands where _finish reads it)
+        src = a.dword(f"x{n_}", xw)
+        a.li("s1", src)
+        a.li("s2", at)
+        for i in range(len(xw)):
+            a.lw("a5", "s1", 4 * i)
+            a.sw("a5", "s2", 4 * i)
+        yp = a.dword(f"y{n_}", yw) if yw is not None else at
+        xp = at
+        if bad and n_ == 0:
+            xp = {"misaligned": at + 2, "low": 16, "high": 0x38000000 - 8}[bad]
+        _syscall(a, code, xp, yp)
+        at += 4 * len(xw)
+        exp += rw
+    _finish(a, out, 4 * nres)
+    return a.elf(), b"".join(struct.pack("<I", v) for v in exp)
+
+
+def curve_ops(bad=None):
+    """BLS12-381 G1 and secp256k1 affine ADD / DOUBLE precompiles: 2G, 3G = 2G + G, 4G = 2(2G), 5G = 4G + G, 7G = 5G + 2G
+    on both curves.  Returns (elf, expected result bytes): the points (x || y little-endian words) go to fd 1.
+    bad: "equal" (ADD of a point to itself), "unreduced" (x + p), "a1" (DOUBLE with a1 != 0) -> the call traps."""
+    a = Asm()
+    exp = []
+    plan = []
+    for name, G, mod, W, c_add, c_dbl in (("bls", BLS_G1, BLS_P, 12, SYS_BLS12381_ADD, SYS_BLS12381_DOUBLE), ("secp", SECP_G, SECP_P, 8, SYS_SECP256K1_ADD, SYS_SECP256K1_DOUBLE)):
+        g2 = ec_double(G, mod)
+        g3 = ec_add(g2, G, mod)
+        g4 = ec_double(g2, mod)
+        g5 = ec_add(g4, G, mod)
+        g7 = ec_add(g5, g2, mod)
+        plan.append((name, W, c_add, c_dbl, G, [g2, g3, g4, g5, g7], mod))
+    nres = sum(2 * W * 5 for _, W, *_ in plan)
+    out = a.dword("out", [0] * (nres + 4))
+    at = out
+    for name, W, c_add, c_dbl, G, pts, mod in plan:
+        pw = lambda pt: words_of(pt[0], W) + words_of(pt[1], W)
+        gaddr = a.dword(f"{name}_g", pw(G))
+        slots = [at + 8 * W * i for i in range(5)]          # 2G, 3G, 4G, 5G, 7G in the output area
+
+        def copy(dst, src):
+            a.li("s1", src)
+            a.li("s2", dst)
+            for i in range(2 * W):
+                a.lw("a5", "s1", 4 * i)
+                a.sw("a5", "s2", 4 * i)
+        copy(slots[0], gaddr)
+        _syscall(a, c_dbl, slots[0], 4 if bad == "a1" and name == "bls" else 0)                 # 2G
+        copy(slots[1], slots[0])
+        if bad == "unreduced" and name == "bls":
+            bogus = a.dword("bogus", words_of(G[0] + mod, W) + words_of(G[1], W))
+            _syscall(a, c_add, slots[1], bogus)
+        _syscall(a, c_add, slots[1], slots[1] if bad == "equal" and name == "bls" else gaddr)    # 3G = 2G + G
+        copy(slots[2], slots[0])
+        _syscall(a, c_dbl, slots[2], 0)                      # 4G
+        copy(slots[3], slots[2])
+        _syscall(a, c_add, slots[3], gaddr)                  # 5G
+        copy(slots[4], slots[3])
+        _syscall(a, c_add, slots[4], slots[0])               # 7G = 5G + 2G
+        for pt in pts:
+            exp += pw(pt)
+        at += 4 * 2 * W * 5
+    _finish(a, out, 4 * nres)
+    return a.elf(), b"".join(struct.pack("<I", v) for v in exp)

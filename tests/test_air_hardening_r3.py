@@ -1,7 +1,7 @@
 """CPU tests (no GPU) of the round-2 advisor's findings on the rv32 AIR:
   * halting is bound to a HALT row: next_pc = HALT_PC = 2^30 is a value no JAL / JALR / branch / sequential row can
     produce, the verifier requires it of the last shard (it used to accept next_pc = 0, which `jalr x0, 0(x0)` reaches);
-  * the registers live at REG_BASE + r = 0x38000000 + r of the memory argument, above every address a load, store or
+  * the registers live at REG_BASE + r = 0x38800000 + r of the memory argument, above every address a load, store or
     precompile can form, so no guest access aliases a register;
   * on JALR rows the byte-offset cells are one-hot as on memory rows, so the ADDR lookup bounds the target's top byte;
   * JAL / branch targets outside the text are BAD_PC in the program table (the executor traps there)."""
@@ -16,7 +16,7 @@ from tests import _orc, guests
 from tools.rvasm import Asm
 
 P = 2013265921
-HALT_PC, REG_BASE, BAD_PC = 1 << 30, 0x38000000, 1
+HALT_PC, REG_BASE, BAD_PC = 1 << 30, 0x38800000, 1
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -46,7 +46,7 @@ def test_constants_agree_between_the_air_and_the_model():
     assert (rv32_model.HALT_PC, rv32_model.REG_BASE, rv32_model.BAD_PC) == (HALT_PC, REG_BASE, BAD_PC)
     # nothing but a HALT row reaches HALT_PC: guest addresses, static targets and JALR targets are below REG_BASE < HALT_PC,
     # the JALR "target" 0 - 1 is p - 1
-    assert REG_BASE == rv32.ADDR_TOP_BYTE << 24 and REG_BASE + 32 <= HALT_PC < P - 1
+    assert REG_BASE == (rv32.ADDR_TOP_BYTE << 24) + (1 << 23) and REG_BASE + 32 <= HALT_PC < P - 1
 
 
 def test_the_last_shard_ends_in_a_halt_row_with_the_sentinel_pc(air):
@@ -132,7 +132,7 @@ def test_jalr_offset_cells_are_one_hot_so_the_target_bound_holds(air):
 
 def test_registers_sit_above_every_guest_address(air):
     """every register-port tuple of the memory bus carries REG_BASE + r; the memory port of a load / store carries an
-    address below REG_BASE; the mem_init table lists the 32 registers last, at 0x38000000 + r"""
+    address below REG_BASE; the mem_init table lists the 32 registers last, at 0x38800000 + r"""
     from tools.airgen import rv32 as airdef
 
     cpu_def = next(c for c in airdef.build().chips if c.name == "cpu")

@@ -16,7 +16,8 @@ def test_air_code_is_up_to_date():
         m = importlib.import_module(f"tools.airgen.{name}").build()
         for path, text in ((("dvt_circuits_amd", "csrc", "gen", f"air_{name}.inc"), emit.emit_cpp(m)),
                            (("oracle", "gen", f"air_{name}.c"), emit.emit_c(m)),
-                           (("dvt_circuits_amd", "csrc", "gen", f"{name}_cols.h"), emit.emit_cols_header(m))):
+                           (("dvt_circuits_amd", "csrc", "gen", f"{name}_cols.h"), emit.emit_cols_header(m)),
+                           (("dvt_circuits_amd", "csrc", "gen", f"{name}_rels.h"), emit.emit_rels_header(m))):
             with open(os.path.join(ROOT, *path)) as f:
                 assert f.read() == text, f"{'/'.join(path)} is stale: run python tools/gen_air.py"
 

@@ -76,20 +76,27 @@ def _encshare_case():
 
 
 @pytest.mark.parametrize("log_shard,which", [(21, "bignum"), (8, "bignum"), (9, "shifts"), (10, "muldiv"), (16, "encshare"),
-                                             (21, "sha_extend"), (9, "sha_extend"), (21, "sha256_precompiled"), (10, "sha256_precompiled")])
+                                             (21, "sha_extend"), (9, "sha_extend"), (21, "sha256_precompiled"), (10, "sha256_precompiled"),
+                                             (21, "field_ops"), (9, "field_ops"), (21, "curve_ops"), (8, "curve_ops"), (13, "horner")])
 def test_rv32_proof_bytes_equal_oracle(log_shard, which):
     from dvt_circuits_amd import capi
 
     stdin = ()
     if which == "encshare":
         elf, want, stdin = _encshare_case()
+    elif which == "horner":
+        # the reference's evaluate_polynomial on two of its known-answer keys through the G1 / Fp precompiles
+        from tests import guests_bls, test_guest_bls_horner as th
+
+        pks = [bytes.fromhex(h) for h in th.HORNER_PKS[:2]]
+        elf, want = guests_bls.horner(pks, [3], subgroup_check=False), th.expected_horner(pks, [3])
     else:
         elf, want = guests.bignum(2, limbs=3) if which == "bignum" else getattr(guests, which)()
     p = capi.Prover('{"fri_queries": %d, "pow_bits": %d, "log_shard_size": %d}' % (Q, POW, log_shard))
     pk, vk = p.setup(elf)
     proof, rep = p.prove_core(pk, stdin)
     ec, pv, gpu_shards = split_container(proof)
-    assert ec == 0 and pv == (want if which in ("bignum", "encshare") else guests.checksum(want))
+    assert ec == 0 and pv == (want if which in ("bignum", "encshare", "horner") else guests.checksum(want))
     cpu_shards = oracle_prove_execution(elf, stdin, log_shard)
     assert len(gpu_shards) == len(cpu_shards) and (len(gpu_shards) > 1) == (log_shard < 21)
     for i, (g, c) in enumerate(zip(gpu_shards, cpu_shards)):

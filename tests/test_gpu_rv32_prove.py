@@ -237,3 +237,24 @@ def test_error_classes(gpu):
     with pytest.raises(capi.DvtError) as e:
         gpu.setup(b"\x7fELF garbage")
     assert e.value.code == capi.DVT_ERR_INPUT
+
+
+def test_reference_horner_kat_is_proven_through_the_curve_precompiles(gpu):
+    """reference crates/dkg/src/dkg_math.rs:281-300: evaluate_polynomial of three public keys at id 1.  The guest decompresses
+    the keys (with the subgroup check), evaluates through the BLS12381 precompile chips and commits the compressed result:
+    the PROVEN public values are the reference's known answer."""
+    from dvt_circuits_amd import capi
+    from tests import guests_bls, test_guest_bls_horner as th
+
+    pks = [bytes.fromhex(h) for h in th.HORNER_PKS]
+    elf = guests_bls.horner(pks, [1, 2], subgroup_check=True)
+    pk, vk = gpu.setup(elf)
+    proof, rep = gpu.prove_core(pk)
+    ok, ec, pv, why = capi.verify(vk, proof, Q, POW)
+    assert ok and ec == 0, why
+    assert pv[:48].hex() == th.HORNER_TARGET and pv == th.expected_horner(pks, [1, 2])
+    # a different claimed result is rejected
+    w = np.frombuffer(proof, np.uint32).copy()
+    w[4] ^= 1
+    assert not capi.verify(vk, w.tobytes(), Q, POW)[0]
+    gpu.pk_free(pk)

@@ -128,7 +128,7 @@ class Interaction:
 
 class PolyRel:
     """A big-integer identity checked limb by limb (see Chip.assert_poly_zero)."""
-    __slots__ = ("name", "terms", "w", "w_off", "sel", "first", "K", "coef_expr")
+    __slots__ = ("name", "terms", "w", "w_off", "sel", "first", "K", "coef_expr", "q", "modulus", "w_lo", "w_top")
 
 
 class Chip:
@@ -181,7 +181,7 @@ class Chip:
         self.assert_zero(x * (x - 1))
 
     # ---- big-integer identities over byte limbs
-    def assert_poly_zero(self, name, terms, sel, cases):
+    def assert_poly_zero(self, name, terms, q, modulus, sel, cases):
         """sum_terms coef * s * A(t) * B(t) = 0 at t = 256, as an identity of INTEGERS, where every term is
         (coef, s, A, B): coef an integer, s a column (a 0/1 selector) or None, A and B limb vectors (lists of columns,
         or lists of integers = constants; B may be None).  Column limbs are range-checked bytes (the caller's duty).
@@ -190,6 +190,8 @@ class Chip:
         one degree <= 3 constraint per coefficient; W_k = w_k - sel * off_k with w_k a new column that the caller
         range-checks to 16 bits (returned).  |c_k| < 2^25 and |256 W_k| < 2^25 keep every equation far below p, so it
         holds over the integers, and so does the identity at t = 256.
+        The identity is "V = 0 (mod modulus)": the term - sel * q(t) * modulus(t) is added here, q a vector of witness
+        columns (range-checked bytes, the caller's duty) and modulus an odd integer given as byte limbs.
         `sel` is the chip's "row is real" selector (the offsets vanish on padding rows); every term must carry a
         selector that is 0 on padding rows.  `cases` lists the selector assignments that can occur ({column: 0/1} dicts,
         e.g. one per operation of the chip): the carry offsets off_k are sized from the extreme values of c_k over them.
@@ -199,6 +201,7 @@ class Chip:
         def vlen(v):
             return len(v)
 
+        terms = list(terms) + [(-1, sel, q, modulus)]
         K = max((vlen(a) + (vlen(b) - 1 if b is not None else 0)) for _, _, a, b in terms)
         # ---- coefficient expressions and their ranges per case
         coef_expr = [Expr.const(0) for _ in range(K)]
@@ -229,7 +232,7 @@ class Chip:
                 wlo[k], whi[k] = min(wlo[k], l), max(whi[k], h)
         assert not self._sealed
         rel = PolyRel()
-        rel.name, rel.terms, rel.sel, rel.K = name, terms, sel, K
+        rel.name, rel.terms, rel.sel, rel.K, rel.q, rel.modulus = name, terms, sel, K, q, modulus
         width = max(whi[k] - wlo[k] for k in range(K - 1))
         assert width < 1 << 17, f"{self.name}.{name}: carries span {width} values"
         for k in range(K):
@@ -240,6 +243,7 @@ class Chip:
         for t in top or []:
             self.assert_zero(t * (t - 1))
         rel.w = [lo16[k] + 65536 * top[k] for k in range(K - 1)] if top else lo16
+        rel.w_lo, rel.w_top = lo16, top
         rel.w_off = [-wlo[k] for k in range(K - 1)]
         rel.coef_expr = coef_expr
         rel.first = None

@@ -111,6 +111,99 @@ def cpp_node(e, nm):
     raise ValueError(e.op)
 
 
+def affine(e):
+    """an expression of degree <= 1 as ({(kind, idx, rot): coefficient}, constant), everything mod P"""
+    if e.op == "const":
+        return {}, e.args[0]
+    if e.op == "var":
+        return {e.args: 1}, 0
+    if e.op == "neg":
+        t, c = affine(e.args[0])
+        return {k: (-v) % P for k, v in t.items()}, (-c) % P
+    (ta, ca), (tb, cb) = affine(e.args[0]), affine(e.args[1])
+    if e.op in ("add", "sub"):
+        sg = 1 if e.op == "add" else -1
+        t = dict(ta)
+        for k, v in tb.items():
+            t[k] = (t.get(k, 0) + sg * v) % P
+        return {k: v for k, v in t.items() if v}, (ca + sg * cb) % P
+    assert e.op == "mul" and (not ta or not tb), "not affine"
+    if not ta:
+        return {k: v * ca % P for k, v in tb.items() if v * ca % P}, ca * cb % P
+    return {k: v * cb % P for k, v in ta.items() if v * cb % P}, ca * cb % P
+
+
+def _shape(it):
+    """interaction as (fixed part, [per value: sorted [(kind, rot, coef, idx)], const])"""
+    vals = []
+    for v in it.vals:
+        t, c = affine(v)
+        vals.append((sorted((k[0], k[2], cf, k[1]) for k, cf in t.items()), c))
+    return (it.bus, it.sign, it.scope, len(it.vals), it.mult.id), vals
+
+
+def _delta(a, b):
+    """index / constant shifts that turn interaction shape a into b, or None"""
+    if a[0] != b[0]:
+        return None
+    out = []
+    for (ta, ca), (tb, cb) in zip(a[1], b[1]):
+        if len(ta) != len(tb) or any(x[:3] != y[:3] for x, y in zip(ta, tb)):
+            return None
+        out.append((tuple(y[3] - x[3] for x, y in zip(ta, tb)), (cb - ca) % P))
+    return out
+
+
+def find_runs(interactions, lo, hi, min_blocks=4):
+    """-> list of (j0, period, blocks) covering disjoint sub-ranges of [lo, hi): `blocks` consecutive groups of `period`
+    interactions that differ only by constant shifts of their column indices and constants"""
+    shapes = {j: _shape(interactions[j]) for j in range(lo, hi)}
+    runs, j = [], lo
+    while j < hi:
+        best = None
+        for p in (1, 2, 3, 4):
+            if j + 2 * p > hi:
+                break
+            d0 = [_delta(shapes[j + t], shapes[j + p + t]) for t in range(p)]
+            if any(d is None for d in d0):
+                continue
+            n = 2
+            while j + (n + 1) * p <= hi and [_delta(shapes[j + (n - 1) * p + t], shapes[j + n * p + t]) for t in range(p)] == d0:
+                n += 1
+            if n >= min_blocks and (best is None or n * p > best[1] * best[2]):
+                best = (j, p, n, d0)
+        if best:
+            runs.append(best)
+            j += best[1] * best[2]
+        else:
+            j += 1
+    return runs
+
+
+def cpp_run(out, interactions, run, machine, need, ind):
+    """a run of interactions as a loop over its blocks"""
+    j0, p, n, deltas = run
+    mults = [need(interactions[j0 + t].mult) for t in range(p)]      # (defined before the loop opens)
+    out.append(f"{ind}_Pragma(\"unroll 1\") for (int i_ = 0; i_ < {n}; i_++) {{   // interactions {j0} .. {j0 + p * n - 1}")
+    for t in range(p):
+        it = interactions[j0 + t]
+        (_, vals), dl = _shape(it), deltas[t]
+        items = []
+        for (terms, const), (didx, dconst) in zip(vals, dl):
+            parts = []
+            for (kind, rot, coef, idx), d in zip(terms, didx):
+                at = f"{idx} + {d} * i_" if d else f"{idx}"
+                acc = f"c.pub({at})" if kind == "pub" else f"c.{kind}({at}, {rot})"
+                parts.append(acc if coef == 1 else f"C::K(0x{coef * R % P:08x}u) * {acc}")
+            if dconst:
+                parts.append(f"c.KI((uint32_t)(({const}ull + {dconst}ull * i_) % {P}ull))")
+            elif const or not parts:
+                parts.append(f"C::K(0x{const * R % P:08x}u)")
+            items.append(" + ".join(parts))
+        out.append(f"{ind}    {{ const T vals[] = {{{', '.join(items)}}}; c.interaction({j0 + t} + {p} * i_, {machine.buses[it.bus]}, {it.sign}, {SCOPE_ID[it.scope]}, {mults[t]}, vals, {len(it.vals)}); }}")
+    out.append(f"{ind}}}")
+
+
 def cpp_poly_group(out, rel, nm, ind):
     """The coefficient constraints [first, first + K) of one polynomial identity, folded at once:
     sum_k alpha^(first + k) (c_k + W_(k-1) - 256 W_k) = alpha^first (C(alpha) + (alpha - 256) W(alpha)), with
@@ -203,14 +296,28 @@ def emit_cpp(machine):
             names = Names()
             out.append(f"        if constexpr (PART == {k}) {{")
             seen = set()
-            for j in range(lo, hi):
+
+            def need(e):
+                for x in topo([e]):
+                    if x.id not in seen:
+                        seen.add(x.id)
+                        out.append("            " + cpp_node(x, names))
+                return names(e)
+
+            # long regular stretches (the byte-range lookups and word accesses of the wide precompile chips) become loops
+            runs = {r[0]: r for r in find_runs(ch.interactions, lo, hi)} if hi - lo >= 16 else {}
+            j = lo
+            while j < hi:
+                if j in runs:
+                    cpp_run(out, ch.interactions, runs[j], machine, need, "            ")
+                    j += runs[j][1] * runs[j][2]
+                    continue
                 it = ch.interactions[j]
-                for e in topo([it.mult] + it.vals):
-                    if e.id not in seen:
-                        seen.add(e.id)
-                        out.append("            " + cpp_node(e, names))
+                for e in [it.mult] + it.vals:
+                    need(e)
                 vals = ", ".join(names(v) for v in it.vals)
                 out.append(f"            {{ const T vals[] = {{{vals}}}; c.interaction({j}, {machine.buses[it.bus]}, {it.sign}, {SCOPE_ID[it.scope]}, {names(it.mult)}, vals, {len(it.vals)}); }}")
+                j += 1
             out.append("        }")
         out.append("    }")
         out.append("};")
@@ -254,29 +361,89 @@ def emit_c(machine):
            '#include "../field.h"', '#include "../air_oracle.h"', ""]
     for ch in machine.chips:
         nm = f"{machine.name}_{ch.name}"
-        out.append(f"static void {nm}_constraints(const bb_t *main_l, const bb_t *main_n, const bb_t *prep_l, const bb_t *prep_n, const bb_t *pub, bb_t *out) {{")
-        out.append("    (void)main_l; (void)main_n; (void)prep_l; (void)prep_n; (void)pub;")
-        names = Names()
-        for e in topo([e for e, _ in ch.constraints]):
-            out.append("    " + c_node(e, names))
-        for i, (e, _) in enumerate(ch.constraints):
-            out.append(f"    out[{i}] = {names(e)};")
-        out.append("}")
+        # (big chips: one function per slice of constraints / interactions — gcc's time grows much faster than linearly with
+        #  the size of a function, and a chip with big-integer identities has ~10^5 expression nodes)
+        args = "const bb_t *main_l, const bb_t *main_n, const bb_t *prep_l, const bb_t *prep_n, const bb_t *pub"
+        unused = "    (void)main_l; (void)main_n; (void)prep_l; (void)prep_n; (void)pub;"
+        CH = 64
+        n_pl = n_plain(ch)
+        rels = getattr(ch, "poly_rels", [])
+        nslices = max(1, -(-n_pl // CH))
+        split = nslices > 1 or bool(rels)
+        for sl in range(nslices):
+            lo, hi = sl * CH, min(n_pl, (sl + 1) * CH)
+            fname = f"{nm}_constraints_{sl}" if split else f"{nm}_constraints"
+            out.append(f"static void {fname}({args}, bb_t *out) {{")
+            out.append(unused + " (void)out;")
+            names = Names()
+            for e in topo([e for e, _ in ch.constraints[lo:hi]]):
+                out.append("    " + c_node(e, names))
+            for i in range(lo, hi):
+                out.append(f"    out[{i}] = {names(ch.constraints[i][0])};")
+            out.append("}")
+        # polynomial identities: the coefficient constraints AS DEFINED (dsl.Chip.assert_poly_zero), coefficient by
+        # coefficient with plain convolution loops — the product folds the same constraints in closed form instead
+        for ri, rel in enumerate(rels):
+            out.append(f"static void {nm}_poly_{ri}({args}, bb_t *out) {{   /* identity '{rel.name}': constraints {rel.first} .. {rel.first + rel.K - 1} */")
+            out.append(unused)
+            names, seen = Names(), set()
+
+            def need(e):
+                for x in topo([e]):
+                    if x.id not in seen:
+                        seen.add(x.id)
+                        out.append("    " + c_node(x, names))
+                return names(e)
+
+            out.append(f"    bb_t c[{rel.K}];")
+            out.append(f"    for (int k = 0; k < {rel.K}; k++) c[k] = 0;")
+            for ti, (coef, sexpr, a, b) in enumerate(rel.terms):
+                sc = need(Expr.wrap(coef) * sexpr)
+                av = ", ".join(f"{x % P}u" if isinstance(x, int) else need(x) for x in a)
+                bv = ", ".join(f"{x % P}u" if isinstance(x, int) else need(x) for x in b) if b is not None else ""
+                out.append(f"    {{ const bb_t a[] = {{{av}}};")
+                if b is None:
+                    out.append(f"      for (int i = 0; i < {len(a)}; i++) c[i] = bb_add(c[i], bb_mul({sc}, a[i])); }}")
+                else:
+                    out.append(f"      const bb_t b[] = {{{bv}}};")
+                    out.append(f"      for (int i = 0; i < {len(a)}; i++) for (int j = 0; j < {len(b)}; j++) c[i + j] = bb_add(c[i + j], bb_mul({sc}, bb_mul(a[i], b[j]))); }}")
+            wv = ", ".join(need(w - rel.sel * off) for w, off in zip(rel.w, rel.w_off))
+            out.append(f"    const bb_t w[] = {{{wv}, 0u}};")
+            out.append(f"    for (int k = 0; k < {rel.K}; k++) out[{rel.first} + k] = bb_sub(bb_add(c[k], k ? w[k - 1] : 0u), bb_mul(256u, w[k]));")
+            out.append("}")
+        if split:
+            out.append(f"static void {nm}_constraints({args}, bb_t *out) {{")
+            for sl in range(nslices):
+                out.append(f"    {nm}_constraints_{sl}(main_l, main_n, prep_l, prep_n, pub, out);")
+            for ri in range(len(rels)):
+                out.append(f"    {nm}_poly_{ri}(main_l, main_n, prep_l, prep_n, pub, out);")
+            out.append("}")
         max_ar = max([len(i.vals) for i in ch.interactions] + [1])
-        out.append(f"static void {nm}_interactions(const bb_t *main_l, const bb_t *main_n, const bb_t *prep_l, const bb_t *prep_n, const bb_t *pub, bb_t *mult, bb_t *vals) {{")
-        out.append("    (void)main_l; (void)main_n; (void)prep_l; (void)prep_n; (void)pub; (void)mult; (void)vals;")
-        roots = []
-        for it in ch.interactions:
-            roots.append(it.mult)
-            roots += it.vals
-        names = Names()
-        for e in topo(roots):
-            out.append("    " + c_node(e, names))
-        for j, it in enumerate(ch.interactions):
-            out.append(f"    mult[{j}] = {names(it.mult)};")
-            for k, v in enumerate(it.vals):
-                out.append(f"    vals[{j * max_ar + k}] = {names(v)};")
-        out.append("}")
+        ICH = 64
+        islices = max(1, -(-len(ch.interactions) // ICH))
+        for sl in range(islices):
+            lo, hi = sl * ICH, min(len(ch.interactions), (sl + 1) * ICH)
+            fname = f"{nm}_interactions" if islices == 1 else f"{nm}_interactions_{sl}"
+            out.append(f"static void {fname}({args}, bb_t *mult, bb_t *vals) {{")
+            out.append(unused + " (void)mult; (void)vals;")
+            roots = []
+            for it in ch.interactions[lo:hi]:
+                roots.append(it.mult)
+                roots += it.vals
+            names = Names()
+            for e in topo(roots):
+                out.append("    " + c_node(e, names))
+            for j in range(lo, hi):
+                it = ch.interactions[j]
+                out.append(f"    mult[{j}] = {names(it.mult)};")
+                for k, v in enumerate(it.vals):
+                    out.append(f"    vals[{j * max_ar + k}] = {names(v)};")
+            out.append("}")
+        if islices > 1:
+            out.append(f"static void {nm}_interactions({args}, bb_t *mult, bb_t *vals) {{")
+            for sl in range(islices):
+                out.append(f"    {nm}_interactions_{sl}(main_l, main_n, prep_l, prep_n, pub, mult, vals);")
+            out.append("}")
         whens = ", ".join(str(WHEN_ID[w]) for _, w in ch.constraints) or "0"
         out.append(f"static const uint8_t {nm}_when[] = {{{whens}}};")
         inter = ", ".join(f"{{{machine.buses[it.bus]}, {it.sign}, {SCOPE_ID[it.scope]}, {len(it.vals)}}}" for it in ch.interactions) or "{0,0,0,0}"
@@ -291,6 +458,60 @@ def emit_c(machine):
     out.append(f"const unsigned orc_machine_{machine.name}_nchips = {len(machine.chips)};")
     out.append("")
     return "\n".join(out)
+
+
+def emit_rels_header(machine):
+    """C++ tables describing every polynomial identity (dsl.Chip.assert_poly_zero) of the machine, for the host trace
+    builder: it fills the quotient q and the carries w of a row from the row's other cells (rv32_bigops.h)."""
+    up = machine.name.upper()
+    out = [f"// GENERATED by tools/airgen (machine '{machine.name}') - do not edit.", "#pragma once", '#include "../polyrel.h"', ""]
+    out.append(f"namespace dvt {{ namespace rels_{machine.name} {{")
+    for ch in machine.chips:
+        rels = getattr(ch, "poly_rels", [])
+        if not rels:
+            continue
+        cu = ch.name
+        for ri, rel in enumerate(rels):
+            pre = f"{cu}_{ri}"
+
+            def col_of(e):
+                assert e.op == "var" and e.args[0] == "main" and e.args[2] == 0, "limb vectors of a polynomial identity are plain main columns"
+                return e.args[1]
+
+            def vec(tag, v):
+                if v is None:
+                    return "{nullptr, nullptr, 0}"
+                if all(isinstance(x, int) for x in v):
+                    out.append(f"static const uint8_t {pre}_{tag}c[] = {{{', '.join(str(x) for x in v)}}};")
+                    return f"{{nullptr, {pre}_{tag}c, {len(v)}}}"
+                out.append(f"static const int16_t {pre}_{tag}v[] = {{{', '.join(str(col_of(x)) for x in v)}}};")
+                return f"{{{pre}_{tag}v, nullptr, {len(v)}}}"
+
+            rows = []
+            for ti, (coef, sexpr, a, b) in enumerate(rel.terms[:-1]):      # (the last term is - sel q modulus)
+                rows.append(f"    {{{coef}, {col_of(sexpr)}, {vec(f't{ti}a', a)}, {vec(f't{ti}b', b)}}},")
+            out.append(f"static const PolyTerm {pre}_terms[] = {{")
+            out += rows
+            out.append("};")
+            nq = len(rel.q)
+            pinv = pow(sum(b << (8 * i) for i, b in enumerate(rel.modulus)), -1, 1 << (8 * nq))
+            out.append(f"static const int16_t {pre}_q[] = {{{', '.join(str(col_of(x)) for x in rel.q)}}};")
+            out.append(f"static const uint8_t {pre}_mod[] = {{{', '.join(str(x) for x in rel.modulus)}}};")
+            out.append(f"static const uint8_t {pre}_pinv[] = {{{', '.join(str((pinv >> (8 * i)) & 0xFF) for i in range(nq))}}};")
+            out.append(f"static const int16_t {pre}_w[] = {{{', '.join(str(col_of(x)) for x in rel.w_lo)}}};")
+            if rel.w_top:
+                out.append(f"static const int16_t {pre}_wb[] = {{{', '.join(str(col_of(x)) for x in rel.w_top)}}};")
+            out.append(f"static const int32_t {pre}_woff[] = {{{', '.join(str(x) for x in rel.w_off)}}};")
+        out.append(f"static const PolyRelDesc {cu}[] = {{")
+        for ri, rel in enumerate(rels):
+            pre = f"{cu}_{ri}"
+            wb = f"{pre}_wb" if rel.w_top else "nullptr"
+            out.append(f'    {{"{rel.name}", {len(rel.terms) - 1}, {pre}_terms, {rel.K}, {pre}_q, {len(rel.q)}, {pre}_mod, {len(rel.modulus)}, {pre}_pinv, {pre}_w, {wb}, {pre}_woff}},')
+        out.append("};")
+        out.append(f"constexpr int {cu}_n = {len(rels)};")
+        out.append("")
+    out.append("}}  // namespace")
+    return "\n".join(out) + "\n"
 
 
 def _ident(name):

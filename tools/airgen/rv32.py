@@ -95,8 +95,10 @@ UNION_W = 26
 ADDR_TOP_BYTE = 0x38
 # The 32 registers are words of the memory argument at REG_BASE + r: ABOVE every address a load, a store or a precompile
 # can form (those are four range-checked bytes with a top byte below ADDR_TOP_BYTE), so no guest access can alias a
-# register (x0 stays 0 whatever pointer the guest dereferences) and nothing has to compare an address with 32.
-REG_BASE = ADDR_TOP_BYTE << 24
+# register (x0 stays 0 whatever pointer the guest dereferences) and nothing has to compare an address with 32.  The 8 MiB gap
+# above ADDR_TOP_BYTE << 24 keeps the multi-word accesses of a precompile whose pointer sits just below the limit (the executor
+# traps on those) away from the registers as well: they land on ordinary words the mem_init table may hold.
+REG_BASE = (ADDR_TOP_BYTE << 24) + (1 << 23)
 # next_pc of a HALT row, and therefore of the last shard: a value no other row can produce (a sequential pc, a static
 # target and a JALR target are all below REG_BASE; p - 1, the JALR "target" 0 - 1, is not 2^30 either), so "the
 # execution halted" is bound to a HALT row, not to control flow that happens to reach address 0.
@@ -928,12 +930,12 @@ def build_fp_op():
     w = ch.assert_poly_zero("rel", [
         (1, is_mul, x, y), (1, is_add, x, None), (1, is_add, y, None),
         (1, is_sub, x, None), (-1, is_sub, y, None), (10, is_sub, Pl, None),       # x - y + 10 p >= 0 for any 384-bit y
-        (-1, is_real, r, None), (-1, is_real, q, Pl)],
-        is_real, [{is_real.id: 1, s.id: 1} for s in (is_add, is_sub, is_mul)])
+        (-1, is_real, r, None)],
+        q, Pl, is_real, [{is_real.id: 1, s.id: 1} for s in (is_add, is_sub, is_mul)])
     for t in w:
         ch.send("byte", [B_U16, 0, t, 0], is_real)
     ch.quotient_parts = 1
-    ch.logup_parts = 10
+    ch.logup_parts = 2
     return ch
 
 
@@ -965,15 +967,15 @@ def build_fp2_op():
     w0 = ch.assert_poly_zero("rel0", [
         (1, is_mul, x0, y0), (-1, is_mul, x1, y1), (1, is_mul, OFF, Pl),
         (1, is_add, x0, None), (1, is_add, y0, None), (1, is_sub, x0, None), (-1, is_sub, y0, None), (10, is_sub, Pl, None),
-        (-1, is_real, r0, None), (-1, is_real, q0, Pl)], is_real, cases)
+        (-1, is_real, r0, None)], q0, Pl, is_real, cases)
     w1 = ch.assert_poly_zero("rel1", [
         (1, is_mul, x0, y1), (1, is_mul, x1, y0),
         (1, is_add, x1, None), (1, is_add, y1, None), (1, is_sub, x1, None), (-1, is_sub, y1, None), (10, is_sub, Pl, None),
-        (-1, is_real, r1, None), (-1, is_real, q1, Pl)], is_real, cases)
+        (-1, is_real, r1, None)], q1, Pl, is_real, cases)
     for t in w0 + w1:
         ch.send("byte", [B_U16, 0, t, 0], is_real)
     ch.quotient_parts = 1
-    ch.logup_parts = 20
+    ch.logup_parts = 4
     return ch
 
 
@@ -1016,17 +1018,17 @@ def build_weierstrass(name, L, Pm, code_add, code_dbl):
     w1 = ch.assert_poly_zero("rel1", [
         (1, is_add, lam, x2), (-1, is_add, lam, x1), (-1, is_add, y2, None), (1, is_add, y1, None),
         (2, is_dbl, lam, y1), (-3, is_dbl, x1, x1),
-        (1, is_real, limbs_of(4 * M, L + 1), Pl), (-1, is_real, q1, Pl)], is_real, cases)
+        (1, is_real, limbs_of(4 * M, L + 1), Pl)], q1, Pl, is_real, cases)
     w2 = ch.assert_poly_zero("rel2", [
         (1, is_real, lam, lam), (-1, is_real, x1, None), (-1, is_add, x2, None), (-1, is_dbl, x1, None), (-1, is_real, x3, None),
-        (4, is_real, Pl, None), (-1, is_real, q2, Pl)], is_real, cases)
+        (4, is_real, Pl, None)], q2, Pl, is_real, cases)
     w3 = ch.assert_poly_zero("rel3", [
         (1, is_real, lam, x1), (-1, is_real, lam, x3), (-1, is_real, y1, None), (-1, is_real, y3, None),
-        (1, is_real, limbs_of(2 * M, L + 1), Pl), (-1, is_real, q3, Pl)], is_real, cases)
+        (1, is_real, limbs_of(2 * M, L + 1), Pl)], q3, Pl, is_real, cases)
     for t in w1 + w2 + w3:
         ch.send("byte", [B_U16, 0, t, 0], is_real)
     ch.quotient_parts = 1
-    ch.logup_parts = 24 if L == 48 else 16
+    ch.logup_parts = 4
     return ch
 
 
@@ -1060,15 +1062,15 @@ def build_mem_init():
     ch.assert_zero(is_img * (1 - is_real))
     ch.assert_zero(is_real.next() * (1 - is_real), "trans")
     # strictly increasing addresses OVER THE INTEGERS: the address itself is four range-checked bytes below 0x39000000
-    # (guest memory below 0x38000000, then the registers), the gap d = addr' - addr - 1 four bytes below 0x38000000,
-    # hence addr + 1 + d < 0x71000000 < p cannot wrap (one initial tuple per address)
+    # (guest memory below 0x38000000, then the registers), and so is the gap d = addr' - addr - 1,
+    # hence addr + 1 + d < 0x72000000 < p cannot wrap (one initial tuple per address)
     ch.assert_zero(is_real.next() * (addr_next - addr - 1 - word([x.next() for x in d])), "trans")
     ch.send("byte", [B_RANGE, 0, ab[0], ab[1]], is_real)
     ch.send("byte", [B_RANGE, 0, ab[2], ab[3]], is_real)
     ch.send("byte", [B_LTU, 1, ab[3], ADDR_TOP_BYTE + 1], is_real)     # (+ 1: the registers at REG_BASE .. REG_BASE + 31)
     ch.send("byte", [B_RANGE, 0, d[0], d[1]], is_real)
     ch.send("byte", [B_RANGE, 0, d[2], d[3]], is_real)
-    ch.send("byte", [B_LTU, 1, d[3], ADDR_TOP_BYTE], is_real)
+    ch.send("byte", [B_LTU, 1, d[3], ADDR_TOP_BYTE + 1], is_real)
     # words outside the program image start with a prover-chosen value: that is how HINT_READ delivers the (private)
     # stdin buffers, as in SP1, whose executor files hinted words as "uninitialized memory" values [EXTERNAL]; .bss is
     # part of the image (zero words), stack and heap are written before they are read
@@ -1082,4 +1084,4 @@ def build_mem_init():
 
 def build():
     return Machine("rv32", [build_program(), build_byte(), build_cpu(), build_mem_image(), build_mem_init(), build_shift(), build_muldiv(),
-                            build_sha_extend(), build_sha_compress()], BUSES)
+                            build_sha_extend(), build_sha_compress(), build_fp_op(), build_fp2_op(), build_bls_g1(), build_secp_k1()], BUSES)

@@ -23,6 +23,7 @@ def main():
             (os.path.join(ROOT, "dvt_circuits_amd", "csrc", "gen", f"air_{name}.inc"), emit.emit_cpp(m)),
             (os.path.join(ROOT, "oracle", "gen", f"air_{name}.c"), emit.emit_c(m)),
             (os.path.join(ROOT, "dvt_circuits_amd", "csrc", "gen", f"{name}_cols.h"), emit.emit_cols_header(m)),
+            (os.path.join(ROOT, "dvt_circuits_amd", "csrc", "gen", f"{name}_rels.h"), emit.emit_rels_header(m)),
         ):
             os.makedirs(os.path.dirname(path), exist_ok=True)
             with open(path, "w") as f:
