@@ -66,6 +66,11 @@ def workload_stdin(participants=0, instance=None):
 
 
 SHA_PRECOMPILES = False   # --sha-precompiles
+CURVE_PRECOMPILES = False  # --curve-precompiles: the per-key point operations are real G1 arithmetic through the BLS12381 precompile chips
+
+
+def guest_kw():
+    return dict(sha_precompiles=SHA_PRECOMPILES, curve_precompiles=CURVE_PRECOMPILES)
 
 
 def fit_constants(stdin_buf, total_shards, sig=0):
@@ -76,7 +81,7 @@ def fit_constants(stdin_buf, total_shards, sig=0):
 
     def cycles(s):
         c = (s, max(1, s // 4), 1)
-        return capi.execute(guests.dkg_like("finalization", *c, sha_precompiles=SHA_PRECOMPILES), [stdin_buf])[1]["cycles"], c
+        return capi.execute(guests.dkg_like("finalization", *c, **guest_kw()), [stdin_buf])[1]["cycles"], c
 
     if sig:
         return cycles(sig)[1]
@@ -132,12 +137,15 @@ def main():
     ap.add_argument("--batch-streams", type=int, default=3, help="--batch: prover handles (one host thread + HIP stream each) per GPU")
     ap.add_argument("--sha-precompiles", action="store_true", help="the guest hashes through SP1's SHA_EXTEND / SHA_COMPRESS precompile "
                     "syscalls (sha_extend / sha_compress chips) instead of RV32IM code; not the default workload")
+    ap.add_argument("--curve-precompiles", action="store_true", help="the guest's per-key point operations are BLS12-381 G1 scalar multiplications "
+                    "through SP1's BLS12381_ADD / _DOUBLE precompile calls (the bls_g1 chip) instead of the multiply-accumulate stand-in")
     ap.add_argument("--exec-threads", type=int, default=0)
     ap.add_argument("--cpu-sizes", type=int, nargs=2, default=[20, 60])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
-    global SHA_PRECOMPILES
+    global SHA_PRECOMPILES, CURVE_PRECOMPILES
     SHA_PRECOMPILES = args.sha_precompiles
+    CURVE_PRECOMPILES = args.curve_precompiles
 
     import torch
 
@@ -172,7 +180,7 @@ def main():
     if args.batch:
         # ---------------------------------------------------------------- B independent proofs ("replicas only")
         consts = fit_constants(stdin_buf, 1, args.sig_iters)
-        elf = guests.dkg_like("finalization", *consts, sha_precompiles=SHA_PRECOMPILES)
+        elf = guests.dkg_like("finalization", *consts, **guest_kw())
         pk, vk = prover.setup(elf)
         inputs = [workload_stdin(args.participants, instance=i) for i in range(args.batch)]
         mine = ranks.shard_of(args.batch)
@@ -180,7 +188,7 @@ def main():
         if mine:
             proof, rep = prover.prove_core(pk, [inputs[mine[0]]])
             ok, ec, pv, why = capi.verify(vk, proof, 100, 16)
-            assert ok and ec == 0 and pv == guests.dkg_like_expected(inputs[mine[0]], "finalization", *consts), f"bench proof rejected: {why}"
+            assert ok and ec == 0 and pv == guests.dkg_like_expected(inputs[mine[0]], "finalization", *consts, curve_precompiles=CURVE_PRECOMPILES), f"bench proof rejected: {why}"
         # S prover handles on this GPU, one host thread each: the host-side execution / upload / proof download of one
         # proof overlaps the kernels of another (independent proofs share nothing; ctypes drops the GIL during the call)
         import threading
@@ -233,9 +241,9 @@ def main():
         # ---------------------------------------------------------------- one execution, shard-parallel
         total_shards = args.shards_per_gpu * world
         consts = fit_constants(stdin_buf, total_shards, args.sig_iters)
-        elf = guests.dkg_like("finalization", *consts, sha_precompiles=SHA_PRECOMPILES)
+        elf = guests.dkg_like("finalization", *consts, **guest_kw())
         pk, vk = prover.setup(elf)
-        want_pv = guests.dkg_like_expected(stdin_buf, "finalization", *consts)
+        want_pv = guests.dkg_like_expected(stdin_buf, "finalization", *consts, curve_precompiles=CURVE_PRECOMPILES)
         state = {}
 
         def prove_once(want_bytes):
@@ -283,7 +291,7 @@ def main():
     #      (always on the reference's example input: an n = 255 input does not fit one shard)
     stdin_buf = workload_stdin(0)
     one = fit_constants(stdin_buf, 1)
-    elf1 = guests.dkg_like("finalization", *one, sha_precompiles=SHA_PRECOMPILES)
+    elf1 = guests.dkg_like("finalization", *one, **guest_kw())
     pk1, _ = prover.setup(elf1)
     job1, rep1 = prover.prepare(pk1, [stdin_buf])
     prover.prove_job(pk1, job1, want_bytes=False)
@@ -339,6 +347,7 @@ def main():
             "stdin_bytes": stdin_bytes,
             "participants": args.participants or 3,
             "sha_precompiles": bool(args.sha_precompiles),
+            "curve_precompiles": bool(args.curve_precompiles),
             "guest_cycles_per_step": cycles,
             "shards_per_step": n_shards,
             "shards_per_gpu": args.shards_per_gpu if not args.batch else None,

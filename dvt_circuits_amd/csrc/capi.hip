@@ -111,6 +111,8 @@ static bool vk_parse(const uint8_t *b, size_t len, VerifyingKey *vk) {
         for (int i = 0; i < 4; i++) { uint32_t v = r.u32(); memcpy(name + 4 * i, &v, 4); }
         vk->machine = machine_by_name(name);
         if (!vk->machine) return false;
+        for (size_t i = strlen(name); i < 16; i++)
+            if (name[i]) return false;   // one encoding per key: the padding after the machine name is zero
         vk->prep_root = r.dg();
         uint32_t n = r.len(64);
         for (uint32_t i = 0; i < n; i++) {

@@ -225,6 +225,91 @@ __global__ void __launch_bounds__(1024) ntt_strided_kernel(const uint32_t *src, 
     }
 }
 
+
+// ---------------------------------------------------------------- P1 / P3, four tile columns per thread
+// The 2^9-row x 16-column tile of a 2^21-row trace (and of its 2^22-row LDE).  One work item = one radix-8 group of FOUR
+// adjacent columns: the 16 columns of a tile row are consecutive n2, so they share every twiddle (a twiddle depends on the
+// row only), one address computation and one twiddle fetch serve four butterflies, and LDS moves 16 bytes per lane
+// (ds_read_b128 / ds_write_b128: twice the bytes per LDS cycle of the 4-byte forms).  256 threads = the 256 work items
+// of a pass.
+// LDS image: 16-byte units, unit (r, c4) = (r << 2) | c4 at physical unit u ^ (((u >> 5) & 3) << 2).  A b128 access is
+// served in 16-lane groups that must hit 16 distinct units mod 16: the lanes of a group take all 16 values of the low
+// four work-item bits; in the passes with 2^lh >= 4 rows per group element those are (c4, two row bits) = unit bits
+// 0..3 directly, in the last pass (lh = 0: unit = block << 5 | j << 2 | c4) the XOR brings block bits 0..1 down.
+constexpr uint32_t V4_L = 9, V4_ROWS = 1u << V4_L, V4_UNITS = V4_ROWS * 4;
+__device__ __forceinline__ uint32_t swzu(uint32_t u) { return u ^ (((u >> 5) & 3u) << 2); }
+
+template <int S>   // DIF stages S, S+1, S+2 of the 2^9-point transform over the rows
+__device__ __forceinline__ void dif3_v4(int4 *sm, const double *tw, uint32_t w) {
+    constexpr uint32_t lh = V4_L - S - 3;
+    const uint32_t c4 = w & 3, rlow = (w >> 2) & ((1u << lh) - 1), blk = w >> (2 + lh);
+    const uint32_t r0 = (blk << (V4_L - S)) | rlow;
+    double v[8][4];
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) {
+        const int4 x = sm[swzu((((j << lh) | r0) << 2) | c4)];
+        v[j][0] = (double)x.x; v[j][1] = (double)x.y; v[j][2] = (double)x.z; v[j][3] = (double)x.w;
+    }
+#pragma unroll
+    for (uint32_t t = 0; t < 3; t++) {
+        const uint32_t dist = 4u >> t;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            if (j & dist) continue;
+            // twiddle exponent: (index mod half) << stage, index mod half = (j mod dist) * 2^lh + rlow
+            const double wv = tw[((((j & (dist - 1)) << lh) | rlow) << (S + t)) & (V4_ROWS / 2 - 1)];
+            const double wp = wv * p2f::PINV;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const double a = v[j][k], b = v[j + dist][k];
+                v[j][k] = a + b;                                   // < 2^34 after three stages
+                v[j + dist][k] = p2f::mm_pre(a - b, wv, wp);       // |a - b| < 2^35: reduced again
+            }
+        }
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) {
+        int4 x;
+        // odd positions left the last stage through a product (already reduced); even ones are sums
+        x.x = to_lds((j & 1) ? v[j][0] : p2f::red(v[j][0])); x.y = to_lds((j & 1) ? v[j][1] : p2f::red(v[j][1]));
+        x.z = to_lds((j & 1) ? v[j][2] : p2f::red(v[j][2])); x.w = to_lds((j & 1) ? v[j][3] : p2f::red(v[j][3]));
+        sm[swzu((((j << lh) | r0) << 2) | c4)] = x;
+    }
+}
+
+// grid.x = row_stride / 16 (tiles along the contiguous axis), grid.y = column; 256 threads; rows = 2^9
+template <bool INVERSE>
+__global__ void __launch_bounds__(256) ntt_strided_v4_kernel(const uint32_t *src, uint32_t *data, size_t col_stride, uint32_t row_stride, NttTables tabs) {
+    __shared__ int4 sm[V4_UNITS];
+    __shared__ double tw[V4_ROWS / 2];
+    uint32_t *col = data + (size_t)blockIdx.y * col_stride;
+    const uint32_t *scol = src + (size_t)blockIdx.y * col_stride;
+    const uint32_t c0 = blockIdx.x << 4, tid = threadIdx.x;
+    tw[tid] = (double)(Lw)tabs.lde_tw_c[V4_ROWS / 2 - 1 + tid];       // w_512^e, e < 256 (canonical, centred)
+#pragma unroll
+    for (uint32_t k = 0; k < V4_UNITS / 256; k++) {
+        const uint32_t u = tid + 256 * k, r = u >> 2, c4 = u & 3;
+        const uint4 x = *reinterpret_cast<const uint4 *>(scol + (size_t)r * row_stride + c0 + 4 * c4);
+        sm[swzu(u)] = make_int4((int)x.x, (int)x.y, (int)x.z, (int)x.w);   // a word in [0, p) is a valid residue in (-p, p)
+    }
+    __syncthreads();
+    dif3_v4<0>(sm, tw, tid);
+    __syncthreads();
+    dif3_v4<3>(sm, tw, tid);
+    __syncthreads();
+    dif3_v4<6>(sm, tw, tid);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < V4_UNITS / 256; k++) {
+        const uint32_t u = tid + 256 * k, q = u >> 2, c4 = u & 3;
+        const uint32_t kf = bitrev(q, V4_L);
+        const uint32_t orow = INVERSE ? (V4_ROWS - kf) & (V4_ROWS - 1) : kf;    // inverse: DFT with the output index negated
+        const int4 x = sm[swzu(u)];
+        *reinterpret_cast<uint4 *>(col + (size_t)orow * row_stride + c0 + 4 * c4) =
+            make_uint4(lds_to_word(x.x), lds_to_word(x.y), lds_to_word(x.z), lds_to_word(x.w));
+    }
+}
+
 // ---------------------------------------------------------------- P2
 // grid.x = N1 (block index k1), grid.y = column.  N2 <= 4096; N2 / 16 <= blockDim.x <= M2.
 __global__ void __launch_bounds__(1024) lde_block_kernel(const uint32_t *in, uint32_t *out, uint32_t log_n, uint32_t log_n1,
@@ -413,7 +498,8 @@ hipError_t launch_coset_lde(hipStream_t st, const NttTables &tabs, uint32_t *d_i
             if (e != hipSuccess) return e;
         }
         dim3 grid((1u << log_n2) >> b, width);
-        ntt_strided_kernel<true><<<grid, T_STRIDED, lds, st>>>(d_in, d_scratch, n, log_n1, 1u << log_n2, b, log_n, tabs);
+        if (log_n1 == V4_L && b == 4) ntt_strided_v4_kernel<true><<<grid, 256, 0, st>>>(d_in, d_scratch, n, 1u << log_n2, tabs);
+        else ntt_strided_kernel<true><<<grid, T_STRIDED, lds, st>>>(d_in, d_scratch, n, log_n1, 1u << log_n2, b, log_n, tabs);
     }
     {
         size_t lds = ((size_t)(2u << log_n2) + (1u << log_n2)) * 4;
@@ -423,7 +509,8 @@ hipError_t launch_coset_lde(hipStream_t st, const NttTables &tabs, uint32_t *d_i
     if (log_n1) {
         size_t lds = ((size_t)(1u << (log_n1 + b)) + (1u << log_n1)) * 4;   // tile words + rows / 2 twiddles as doubles
         dim3 grid((2u << log_n2) >> b, width);
-        ntt_strided_kernel<false><<<grid, T_STRIDED, lds, st>>>(d_out, d_out, 2 * n, log_n1, 2u << log_n2, b, log_n + 1, tabs);
+        if (log_n1 == V4_L && b == 4) ntt_strided_v4_kernel<false><<<grid, 256, 0, st>>>(d_out, d_out, 2 * n, 2u << log_n2, tabs);
+        else ntt_strided_kernel<false><<<grid, T_STRIDED, lds, st>>>(d_out, d_out, 2 * n, log_n1, 2u << log_n2, b, log_n + 1, tabs);
     }
     return hipGetLastError();
 }

@@ -66,6 +66,8 @@ def _lib(orc):
     lib.orc_eval_columns.argtypes = [u32p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]
     lib.orc_reduced_opening.argtypes = [C.POINTER(u32p), C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p, u32p, u32p, u32p, u32p]
     lib.orc_fri_fold.argtypes = [u32p, C.c_uint32, u32p, u32p, u32p]
+    lib.orc_pow_grind.argtypes = [u32p, C.c_uint32, C.c_uint32]
+    lib.orc_pow_grind.restype = C.c_uint32
     return lib
 
 
@@ -146,9 +148,22 @@ def prep_root_of(chips):
     return orc.merkle_commit([orc.coset_lde(_a(c["prep"]), 1, G) for c in air_chips])[-1].tolist()
 
 
+STAGE_SECONDS = {}     # wall time of the stages of the LAST prove_shard call (bench.py prints them beside the GPU's stage_ms)
+
+
 def prove_shard(machine, chips, pubs, num_queries, pow_bits, perm_challenges=None, prep_chips=None):
     """chips: list of dict(chip_id, main [w][N], prep [w][N]) sorted by chip id (every chip of the shard).
     Returns the shard proof bytes and the preprocessed root (8 ints)."""
+    import time
+
+    t_mark = [time.perf_counter()]
+    STAGE_SECONDS.clear()
+
+    def lap(name):
+        now = time.perf_counter()
+        STAGE_SECONDS[name] = STAGE_SECONDS.get(name, 0.0) + now - t_mark[0]
+        t_mark[0] = now
+
     orc = _orc.load()
     air = _orc.air(machine)
     lib = _lib(orc)
@@ -173,6 +188,7 @@ def prove_shard(machine, chips, pubs, num_queries, pow_bits, perm_challenges=Non
     prep_layers, prep_root = commit([l for _, l in prep_mats]) if prep_mats else (None, [0] * 8)
     prep_log_h = max([c["log_n"] + 1 for c, _ in prep_mats], default=0)
 
+    lap("setup_prep")
     ch = Challenger(orc)
     ch.observe(prep_root)
     ch.observe([len(cs)])
@@ -185,6 +201,7 @@ def prove_shard(machine, chips, pubs, num_queries, pow_bits, perm_challenges=Non
     ch.observe(main_root)
     ch.observe([npub])
     ch.observe(pubs[:npub])
+    lap("commit_main")
     # 2. permutation
     if perm_challenges is not None:   # common to all shards; bound into this shard's transcript
         perm_alpha, beta = [int(x) for x in perm_challenges[0]], [int(x) for x in perm_challenges[1]]
@@ -205,6 +222,7 @@ def prove_shard(machine, chips, pubs, num_queries, pow_bits, perm_challenges=Non
     ch.observe(perm_root)
     for c in cs:
         ch.observe(c["cumsum"])
+    lap("permutation")
     # 3. quotient
     alpha = ch.sample_ext()
     for c in cs:
@@ -219,6 +237,7 @@ def prove_shard(machine, chips, pubs, num_queries, pow_bits, perm_challenges=Non
         c["quot_lde"] = np.concatenate([orc.coset_lde(out[:4], 1, 1), orc.coset_lde(out[4:], 1, w2inv)])
     quot_layers, quot_root = commit([c["quot_lde"] for c in cs])
     ch.observe(quot_root)
+    lap("quotient")
     # 4. openings
     zeta = ch.sample_ext()
 
@@ -240,6 +259,7 @@ def prove_shard(machine, chips, pubs, num_queries, pow_bits, perm_challenges=Non
         for k in ("prep_l", "prep_n", "main_l", "main_n", "perm_l", "perm_n", "quot"):
             for v in c["open"][k]:
                 ch.observe(v)
+    lap("openings")
     # 5. FRI input
     alpha_fri = ch.sample_ext()
     ro = {}
@@ -287,13 +307,7 @@ def prove_shard(machine, chips, pubs, num_queries, pow_bits, perm_challenges=Non
     # 7. proof of work: smallest witness
     base = list(ch.state)
     base[: len(ch.inp)] = ch.inp
-    pos, mask, w = len(ch.inp), (1 << pow_bits) - 1, 0
-    while True:
-        s = list(base)
-        s[pos] = w
-        if orc.permute(np.array(s, np.uint32))[7] & mask == 0:
-            break
-        w += 1
+    w = int(lib.orc_pow_grind(_p(np.array(base, np.uint32)), len(ch.inp), pow_bits))     # smallest witness (C + OpenMP)
     ch.observe([w])
     assert ch.sample_bits(pow_bits) == 0
     idx = [ch.sample_bits(hmax) for _ in range(num_queries)]
@@ -326,4 +340,5 @@ def prove_shard(machine, chips, pubs, num_queries, pow_bits, perm_challenges=Non
             j = q & ((1 << lm) - 1)
             W.ef(fri_vecs[k][j ^ (1 << (lm - 1))].tolist())
             W.dgs(tree_path(fri_layers[k], lm - 1, q))
+    lap("fri")
     return W.bytes(), prep_root
