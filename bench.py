@@ -110,6 +110,7 @@ def cpu_baseline(stdin_buf, sizes):
         gc = _oracle_prover.global_challenges(_oracle_prover.prep_root_of(chips), [_oracle_prover.main_root(chips) + [int(x) for x in pubs]])
         _oracle_prover.prove_shard("rv32", chips, pubs, 100, 16, perm_challenges=gc)
         pts.append((cyc, time.perf_counter() - t))
+        stage_s = {k: round(v, 3) for k, v in _oracle_prover.STAGE_SECONDS.items()}
     (c0, t0), (c1, t1) = pts
     cores = int(_orc.load().lib.orc_num_threads())  # OpenMP threads the oracle actually ran with
     return {
@@ -118,9 +119,12 @@ def cpu_baseline(stdin_buf, sizes):
         "cores": cores,
         "kind": "port",
         "parity": "unpinned against stock SP1 (the reference's prover cannot be built here); the GPU proof bytes are checked against this port",
-        "sample": "in-repo CPU restatement (oracle, C + OpenMP, Python-orchestrated; not SP1): the bench guest at %d cycles (%.1f s) and %d "
-                  "cycles (%.1f s), 100 FRI queries, 16 PoW bits; value = marginal rate between the two (the 2^16-row byte table is a "
-                  "fixed cost); whole-sample rate of the larger one = %.0f cycles/s" % (c0, t0, c1, t1, c1 / t1),
+        "sample": "in-repo CPU restatement (oracle: every stage and the PoW grind in C + OpenMP, sequenced from Python; not SP1): the bench "
+                  "guest at %d cycles (%.1f s) and %d cycles (%.1f s), 100 FRI queries, 16 PoW bits; value = marginal rate between the "
+                  "two (the 2^16-row byte table is a fixed cost); whole-sample rate of the larger one = %.0f cycles/s" % (c0, t0, c1, t1, c1 / t1),
+        "whole_sample_value": c1 / t1,
+        # wall seconds of the stages of the larger sample (the stages of stage_ms, same names): where the CPU port spends its time
+        "stage_s": stage_s,
     }
 
 
@@ -140,7 +144,8 @@ def main():
     ap.add_argument("--curve-precompiles", action="store_true", help="the guest's per-key point operations are BLS12-381 G1 scalar multiplications "
                     "through SP1's BLS12381_ADD / _DOUBLE precompile calls (the bls_g1 chip) instead of the multiply-accumulate stand-in")
     ap.add_argument("--exec-threads", type=int, default=0)
-    ap.add_argument("--cpu-sizes", type=int, nargs=2, default=[20, 60])
+    ap.add_argument("--cpu-sizes", type=int, nargs=2, default=[30, 95], help="guest iteration constants of the two CPU-baseline samples "
+                    "(95 = a little over 1 M cycles: the fixed costs are then below a fifth of the larger sample)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     global SHA_PRECOMPILES, CURVE_PRECOMPILES
@@ -320,7 +325,7 @@ def main():
     # compulsory streams of the whole shard, each counted once
     shard_alg = 36 * ks["cells_main"] + 36 * ks["cells_perm"] + 28 * ks["cells_quotient"] + 24 * ks["cells_prep"]
     pmc = {}
-    for name in ("r2_pmc_k1_traffic.json", "r1c_pmc_k1_traffic.json"):
+    for name in ("r3_pmc_k1_traffic.json", "r2_pmc_k1_traffic.json", "r1c_pmc_k1_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             pmc["_file"] = name
@@ -360,7 +365,7 @@ def main():
         }, **extra),
         "roofline": {
             "bound": "hbm",
-            "kernel": "K1 coset LDE (ntt_strided_kernel<true> + lde_block_kernel + ntt_strided_kernel<false>), %d calls per proof" % ks["lde_calls"],
+            "kernel": "K1 coset LDE (ntt_strided_v4_kernel<true> + lde_block2_kernel + ntt_strided_v4_kernel<false>), %d calls per proof" % ks["lde_calls"],
             "achieved": lde_gbps,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",

@@ -195,6 +195,9 @@ class Engine {
 
     Arena arena;
     DevPool pool;
+    // K5 selector tables, one per trace height this prover has seen ([3][2N] words each, stark.cuh QuotientArgs::sel)
+    uint32_t *sel_tables[32] = {};
+    const uint32_t *selector_table(const QuotientArgs &qa);
 
   private:
     char *d_ring = nullptr, *h_ring = nullptr;

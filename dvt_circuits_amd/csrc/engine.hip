@@ -84,6 +84,7 @@ void Engine::shutdown() {
     arena.release();
     pool.trim();
     ntt_tables_destroy(&tabs);
+    for (auto &t : sel_tables) { if (t) (void)hipFree(t); t = nullptr; }
     if (d_ring) (void)hipFree(d_ring);
     if (h_ring) (void)hipHostFree(h_ring);
     if (h_down) (void)hipHostFree(h_down);
@@ -118,6 +119,23 @@ bool Engine::download(void *host, const void *dev, size_t bytes) {
     HIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     return true;
+}
+
+const uint32_t *Engine::selector_table(const QuotientArgs &qa) {
+    if (qa.log_n >= 32) return nullptr;
+    if (!sel_tables[qa.log_n]) {
+        // (kept for the life of the prover: 24 bytes per trace row of that height; a failed allocation only means the
+        //  kernels keep computing the selectors themselves)
+        const size_t m = (size_t)2 << qa.log_n;
+        uint32_t *t = nullptr;
+        if (hipMalloc(&t, 3 * m * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        QuotientArgs a = qa;
+        a.sel = nullptr;
+        selector_table_kernel<0><<<(unsigned)((m + 255) / 256), 256, 0, stream>>>(a, t);
+        if (hipGetLastError() != hipSuccess) { (void)hipFree(t); return nullptr; }
+        sel_tables[qa.log_n] = t;
+    }
+    return sel_tables[qa.log_n];
 }
 
 bool Engine::commit_tree(const std::vector<DevMat> &mats, uint32_t *d_digests) {
@@ -586,6 +604,7 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
         qa.w_inv = inv(two_adic_generator(s.log_n));
         qa.log_n = s.log_n;
         qa.tabs = tabs;
+        qa.sel = selector_table(qa);
         HIPCHK(s.d->launch_quotient(stream, qa));
         HIPCHK(lde(s.quot, d_scratch, s.quot_lde, 4, s.log_n, 1));
         HIPCHK(lde(s.quot + 4 * s.n, d_scratch, s.quot_lde + 8 * s.n, 4, s.log_n, 2));

@@ -389,6 +389,159 @@ __global__ void __launch_bounds__(1024) lde_block_kernel(const uint32_t *in, uin
     }
 }
 
+
+// ---------------------------------------------------------------- P2, two trace columns per workgroup
+// The same transform as lde_block_kernel (below) for log_n2 = 12 on TWO adjacent trace columns at once: element i of
+// both columns lives in one 8-byte LDS slot (int2), so the swizzle, the lane -> work-item maps and every twiddle / scaling
+// factor (functions of the position only) are computed once for two butterflies, LDS moves 8 bytes per lane
+// (ds_read_b64 / ds_write_b64: twice the bytes per LDS cycle of the 4-byte forms; the bank of an 8-byte slot pair is
+// (i mod 32), so the 32-bank analysis of swz() carries over), and the per-thread geometric twiddle sequences of the
+// load / store loops are shared.  64 KB tile + 16 KB twiddles: two workgroups (four columns) per CU.
+template <int R, int L, int S, int TWS>
+__device__ __forceinline__ void dif_pass2(int2 *sm, const Lw *tw, uint32_t tid, uint32_t nt) {
+    constexpr uint32_t G = 1u << R, lh = L - S - R, work = 1u << (L - R);
+    for (uint32_t w = tid; w < work; w += nt) {
+        const uint32_t r = w & ((1u << lh) - 1);
+        const uint32_t blk = lane_block<R>(w >> lh, lh, S);
+        const uint32_t base = swz((blk << (L - S)) | r);
+        double v[G][2];
+#pragma unroll
+        for (uint32_t j = 0; j < G; j++) {
+            const int2 x = sm[base ^ swz(j << lh)];
+            v[j][0] = (double)x.x; v[j][1] = (double)x.y;
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < (uint32_t)R; t++) {
+            const uint32_t dist = G >> (t + 1);
+            const uint32_t twr = swz((r << (S + t)) << TWS);
+#pragma unroll
+            for (uint32_t j = 0; j < G; j++) {
+                if (j & dist) continue;
+                const double wv = (double)tw[twr ^ swz((((j & (dist - 1)) << lh) << (S + t)) << TWS)];
+                const double wp = wv * p2f::PINV;
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const double a = v[j][c], b = v[j + dist][c];
+                    v[j][c] = a + b;
+                    v[j + dist][c] = p2f::mm_pre(a - b, wv, wp);
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < G; j++)
+            sm[base ^ swz(j << lh)] = make_int2(to_lds((j & 1) ? v[j][0] : p2f::red(v[j][0])), to_lds((j & 1) ? v[j][1] : p2f::red(v[j][1])));
+    }
+}
+template <int R, int L, int S, int TWS>
+__device__ __forceinline__ void dit_pass2(int2 *sm, const Lw *tw, uint32_t tid, uint32_t nt) {
+    constexpr uint32_t G = 1u << R, work = 1u << (L - R), blk_bits = L - R - S;
+    for (uint32_t g = tid; g < work; g += nt) {
+        const uint32_t r = g & ((1u << S) - 1);
+        const uint32_t blk = lane_block<R>(g >> S, S, blk_bits);
+        const uint32_t base = swz((blk << (S + R)) | r);
+        double v[G][2];
+#pragma unroll
+        for (uint32_t j = 0; j < G; j++) {
+            const int2 x = sm[base ^ swz(j << S)];
+            v[j][0] = (double)x.x; v[j][1] = (double)x.y;
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < (uint32_t)R; t++) {
+            const uint32_t dist = 1u << t;
+            const uint32_t twr = swz((r << (L - 1 - S - t)) << TWS);
+#pragma unroll
+            for (uint32_t j = 0; j < G; j++) {
+                if (j & dist) continue;
+                const double wv = (double)tw[twr ^ swz((((j & (dist - 1)) << S) << (L - 1 - S - t)) << TWS)];
+                const double wp = wv * p2f::PINV;
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const double a = v[j][c], b = p2f::mm_pre(v[j + dist][c], wv, wp);   // |v| < 2^33
+                    v[j][c] = a + b;
+                    v[j + dist][c] = a - b;
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < G; j++) sm[base ^ swz(j << S)] = make_int2(to_lds(p2f::red(v[j][0])), to_lds(p2f::red(v[j][1])));
+    }
+}
+template <bool DIF, int L, int FIRST, int COUNT, int TWS>
+__device__ __forceinline__ void run_stages2(int2 *sm, const Lw *tw, uint32_t tid, uint32_t nt) {
+    if constexpr (COUNT > 0) {
+        constexpr int R = COUNT >= 3 ? 3 : COUNT;
+        if constexpr (DIF) dif_pass2<R, L, FIRST, TWS>(sm, tw, tid, nt);
+        else dit_pass2<R, L, FIRST, TWS>(sm, tw, tid, nt);
+        __syncthreads();
+        run_stages2<DIF, L, FIRST + R, COUNT - R, TWS>(sm, tw, tid, nt);
+    }
+}
+
+// grid.x = N1, grid.y = column pairs; log_n2 = 12, 512 threads; columns 2 y and 2 y + 1 (both exist)
+__global__ void __launch_bounds__(512) lde_block2_kernel(const uint32_t *in, uint32_t *out, uint32_t log_n, uint32_t log_n1,
+                                                       uint32_t shift_mode, NttTables tabs) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    constexpr uint32_t log_n2 = 12, n2 = 1u << log_n2, m2 = n2 * 2, log_m2 = log_n2 + 1;
+    const uint32_t log_m = log_n + 1;
+    int2 *sm = reinterpret_cast<int2 *>(lds);
+    Lw *tw = reinterpret_cast<Lw *>(sm + m2);  // n2 entries: w_M2^e, e < M2/2 (canonical)
+    const uint32_t k1 = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t *src0 = in + ((size_t)(2 * blockIdx.y) << log_n) + ((size_t)k1 << log_n2), *src1 = src0 + ((size_t)1 << log_n);
+    uint32_t *dst0 = out + ((size_t)(2 * blockIdx.y) << log_m) + ((size_t)k1 << log_m2), *dst1 = dst0 + ((size_t)1 << log_m);
+    const uint32_t *W = tabs.lde_tw_c + (n2 - 1);
+    const uint32_t *T = tabs.lde_scale_c + ((size_t)(shift_mode * LDE_MAX_LOG + log_n) << 12);
+    for (uint32_t e = tid; e < n2; e += nt) tw[swz(e)] = (Lw)W[e];
+    if (log_n1 == 0 || k1 == 0) {
+        for (uint32_t i = tid; i < n2; i += nt) sm[swz(i)] = make_int2((Lw)src0[i], (Lw)src1[i]);
+    } else {
+        const uint32_t nn = 1u << log_n;
+        double cur = tid ? centred(root_pow24(tabs, (nn - tid * k1) << (24 - log_n))) : 1.0;
+        const double step = centred(root_pow24(tabs, (nn - nt * k1) << (24 - log_n)));
+        for (uint32_t i = tid; i < n2; i += nt) {
+            const double cp = cur * p2f::PINV;
+            sm[swz(i)] = make_int2(to_lds(p2f::mm_pre((double)src0[i], cur, cp)), to_lds(p2f::mm_pre((double)src1[i], cur, cp)));
+            cur = p2f::mm(cur, step);
+        }
+    }
+    __syncthreads();
+    run_stages2<true, 12, 0, 12, 1>(sm, tw, tid, nt);
+    int2 regs[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const uint32_t q = tid + t * nt;
+        const double sc = (double)(Lw)T[q], sp = sc * p2f::PINV;
+        const int2 x = sm[swz(q)];
+        regs[t] = make_int2(to_lds(p2f::mm_pre((double)x.x, sc, sp)), to_lds(p2f::mm_pre((double)x.y, sc, sp)));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const uint32_t q = tid + t * nt;
+        const uint32_t k2 = (n2 - bitrev(q, log_n2)) & (n2 - 1);
+        const uint32_t d = 2 * bitrev(k2, log_n2);
+        sm[swz(d)] = regs[t];
+        sm[swz(d) ^ 1] = regs[t];
+    }
+    __syncthreads();
+    run_stages2<false, 13, 1, 12, 0>(sm, tw, tid, nt);
+    if (log_n1 == 0) {
+        for (uint32_t j2 = tid; j2 < m2; j2 += nt) { const int2 x = sm[swz(j2)]; dst0[j2] = lds_to_word(x.x); dst1[j2] = lds_to_word(x.y); }
+        return;
+    }
+    Fp c0 = root_pow24(tabs, (tid * k1) << (24 - log_m));
+    if (shift_mode == 0) c0 = c0 * shift_pow(tabs, k1);
+    else if (shift_mode == 2 && k1) c0 = c0 * root_pow24(tabs, ((2u << log_n) - k1) << (24 - log_m));
+    double cur = centred(c0);
+    const double step = centred(root_pow24(tabs, (nt * k1) << (24 - log_m)));
+    for (uint32_t j2 = tid; j2 < m2; j2 += nt) {
+        const double cp = cur * p2f::PINV;
+        const int2 x = sm[swz(j2)];
+        dst0[j2] = p2f::fix(p2f::mm_pre((double)x.x, cur, cp));
+        dst1[j2] = p2f::fix(p2f::mm_pre((double)x.y, cur, cp));
+        cur = p2f::mm(cur, step);
+    }
+}
+
 // ---------------------------------------------------------------- elementwise representation change
 __global__ void to_internal_kernel(uint32_t *d, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
@@ -502,9 +655,25 @@ hipError_t launch_coset_lde(hipStream_t st, const NttTables &tabs, uint32_t *d_i
         else ntt_strided_kernel<true><<<grid, T_STRIDED, lds, st>>>(d_in, d_scratch, n, log_n1, 1u << log_n2, b, log_n, tabs);
     }
     {
-        size_t lds = ((size_t)(2u << log_n2) + (1u << log_n2)) * 4;
-        dim3 grid(1u << log_n1, width);
-        lde_block_kernel<<<grid, T_BLOCK, lds, st>>>(log_n1 ? d_scratch : d_in, d_out, log_n, log_n1, shift_mode, tabs);
+        const uint32_t *p2_in = log_n1 ? d_scratch : d_in;
+        uint32_t done = 0;
+        if (log_n2 == 12 && width >= 2) {   // column pairs through the two-column kernel
+            static bool attr_set = false;
+            const size_t lds2 = ((size_t)(2u << log_n2) * 2 + (1u << log_n2)) * 4;   // 64 KB of int2 + 16 KB of twiddles
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lde_block2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                if (e != hipSuccess) return e;
+                attr_set = true;
+            }
+            dim3 grid2(1u << log_n1, width / 2);
+            lde_block2_kernel<<<grid2, 512, lds2, st>>>(p2_in, d_out, log_n, log_n1, shift_mode, tabs);
+            done = width & ~1u;
+        }
+        if (done < width) {
+            size_t lds = ((size_t)(2u << log_n2) + (1u << log_n2)) * 4;
+            dim3 grid(1u << log_n1, width - done);
+            lde_block_kernel<<<grid, T_BLOCK, lds, st>>>(p2_in + ((size_t)done << log_n), d_out + ((size_t)done << (log_n + 1)), log_n, log_n1, shift_mode, tabs);
+        }
     }
     if (log_n1) {
         size_t lds = ((size_t)(1u << (log_n1 + b)) + (1u << log_n1)) * 4;   // tile words + rows / 2 twiddles as doubles

@@ -299,7 +299,35 @@ struct QuotientArgs {
     Fp w_inv;                  // omega_N^-1
     uint32_t log_n;
     NttTables tabs;
+    // per-height selector table [3][2N] (sel_first, sel_last, sel_trans on the LDE rows), built once per prover by
+    // selector_table_kernel: every launch of every chip of that height reads three coalesced words per row instead of
+    // computing x = g w^i (two table gathers, two products) and inverting (x - 1)(x - w^-1) (about sixty products) —
+    // the cpu chip's quotient is nine launches.  nullptr: computed in the kernel (the first proof of a height).
+    const uint32_t *sel = nullptr;
 };
+
+// the three selectors of one LDE row (what quotient_kernel used to compute inline)
+__device__ __forceinline__ void selectors_of_row(const QuotientArgs &a, size_t i, Fp *sel_first, Fp *sel_last, Fp *sel_trans) {
+    const uint32_t log_m = a.log_n + 1;
+    // x = g * w_{2N}^i
+    Fp x = Fp::raw(a.tabs.sh_lo[1]) * (Fp::raw(a.tabs.tw_hi[((uint32_t)i << (24 - log_m)) >> 12]) *
+                                        Fp::raw(a.tabs.tw_lo[((uint32_t)i << (24 - log_m)) & 4095]));
+    const Fp zh = (i & 1) ? a.z_odd : a.z_even;
+    Fp d1 = x - Fp::one(), d2 = x - a.w_inv;
+    Fp pinv = inv(d1 * d2);
+    *sel_first = zh * (pinv * d2);
+    *sel_last = zh * (pinv * d1);
+    *sel_trans = d2;
+}
+template <int UNUSED>   // (a template only so that the header may define it in several translation units)
+__global__ void __launch_bounds__(256) selector_table_kernel(QuotientArgs a, uint32_t *out) {
+    const size_t m = (size_t)2 << a.log_n;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    Fp f, l, t;
+    selectors_of_row(a, i, &f, &l, &t);
+    out[i] = f.v; out[m + i] = l.v; out[2 * m + i] = t.v;
+}
 
 struct QuotAccess {
     const QuotientArgs &a;
@@ -330,17 +358,13 @@ __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
     f.beta_d = a.beta_d;
     f.perm_alpha = a.perm_alpha;
     f.cum_over_n = a.cum_over_n;
-    // x = g * w_{2N}^i
-    const uint32_t log_m = a.log_n + 1;
-    Fp x = Fp::raw(a.tabs.sh_lo[1]) * (Fp::raw(a.tabs.tw_hi[((uint32_t)i << (24 - log_m)) >> 12]) *
-                                        Fp::raw(a.tabs.tw_lo[((uint32_t)i << (24 - log_m)) & 4095]));
     const bool odd = i & 1;
-    Fp zh = odd ? a.z_odd : a.z_even, zhinv = odd ? a.zinv_odd : a.zinv_even;
-    Fp d1 = x - Fp::one(), d2 = x - a.w_inv;
-    Fp pinv = inv(d1 * d2);
-    f.sel_first = zh * (pinv * d2);
-    f.sel_last = zh * (pinv * d1);
-    f.sel_trans = d2;
+    const Fp zhinv = odd ? a.zinv_odd : a.zinv_even;
+    if (a.sel) {
+        f.sel_first = Fp::raw(a.sel[i]); f.sel_last = Fp::raw(a.sel[m + i]); f.sel_trans = Fp::raw(a.sel[2 * m + i]);
+    } else {
+        selectors_of_row(a, i, &f.sel_first, &f.sel_last, &f.sel_trans);
+    }
     Fp4 q = f.template run<PART>() * zhinv;
     const size_t n = m >> 1;
     uint32_t *o = a.out + (odd ? 4 * n : 0) + (i >> 1);

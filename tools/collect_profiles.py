@@ -21,6 +21,10 @@ import sys
 
 tag, stats_dir, fetch_dir, write_dir, n_proofs = sys.argv[1:6]
 n_proofs = int(n_proofs)
+# optional: trace elements that go through K1 per shard proof (bench line: roofline.alg_bytes_per_proof / 12).  With it the
+# FETCH_SIZE correction of each pass is CALIBRATED on the pass's own byte model (P1 reads 4 B per element, P2 4 B, P3 8 B:
+# every input byte is read once) as MI355X_MICROARCH.md asks for access patterns it has not calibrated itself
+elements = float(sys.argv[6]) if len(sys.argv) > 6 else 0.0
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
 
 
@@ -48,10 +52,21 @@ with open(os.path.join(ROOT, f"{tag}_pmc_fetch_write_by_kernel.csv"), "w") as f:
         f.write('"%s",%d,%.1f,%.1f\n' % (k, nf[k], fetch[k], write.get(k, 0.0)))
 k1 = []
 total = 0.0
-for name, label, corr in (("void dvt::ntt_strided_kernel<true>", "P1 ntt_strided<inverse>", 1), ("dvt::lde_block_kernel", "P2 lde_block", 2),
-                          ("void dvt::ntt_strided_kernel<false>", "P3 ntt_strided<forward>", 1)):
+# (round 3: the strided passes take four tile columns per thread, P2 two trace columns per workgroup; the few launches of the
+#  older kernels on odd widths / other heights are added to their pass)
+for names, label, corr in ((("void dvt::ntt_strided_v4_kernel<true>", "void dvt::ntt_strided_kernel<true>"), "P1 ntt_strided<inverse>", 1),
+                           (("dvt::lde_block2_kernel", "dvt::lde_block_kernel"), "P2 lde_block", 2),
+                           (("void dvt::ntt_strided_v4_kernel<false>", "void dvt::ntt_strided_kernel<false>"), "P3 ntt_strided<forward>", 1)):
+    name = names[0]
+    for extra_name in names[1:]:
+        fetch[name] += fetch.get(extra_name, 0.0)
+        write[name] = write.get(name, 0.0) + write.get(extra_name, 0.0)
+        nf[name] += nf.get(extra_name, 0)
     rd = fetch[name] * 1024 / n_proofs
     wr = write[name] * 1024 / n_proofs
+    if elements:
+        model = elements * (8 if label.startswith("P3") else 4)
+        corr = 2 if rd < 0.75 * model else 1       # raw counter at about half the bytes the pass must read: the gfx950 wide-read tally
     k1.append(dict(kernel=label, launches_per_proof=nf[name] / n_proofs, fetch_raw_bytes=rd, fetch_correction=corr, read_bytes=rd * corr, write_bytes=wr))
     total += rd * corr + wr
 json.dump(dict(k1_hbm_bytes_per_proof=total, proofs_in_run=n_proofs,
