@@ -33,6 +33,7 @@ struct PolyRelDesc {
     const uint8_t *pinv;     // modulus^-1 mod 256^nq
     const int16_t *w, *wb;   // carry columns (low 16 bits; top bit or nullptr)
     const int32_t *w_off;
+    const int16_t *modv;     // non-null: the modulus is a vector of the row's own cells (mod / pinv are null): q by long division
 };
 
 constexpr int POLY_MAX_K = 200;
@@ -53,26 +54,70 @@ bool solve_poly_rel(const PolyRelDesc &d, Row &row) {
             else for (int j = 0; j < tm.b.len; j++) c[i + j] += ai * limb(tm.b, j);
         }
     }
-    // the low nq digits of V
-    uint8_t low[POLY_MAX_K], q[POLY_MAX_K];
-    int64_t t = 0;
-    for (int k = 0; k < d.nq; k++) {
-        if (k < d.K) t += c[k];
-        low[k] = (uint8_t)(t & 255);
-        t = (t - low[k]) / 256;
-    }
-    // q = low * pinv mod 256^nq
-    uint64_t carry = 0;
-    for (int k = 0; k < d.nq; k++) {
-        uint64_t s = carry;
-        for (int i = 0; i <= k; i++) s += (uint64_t)low[i] * d.pinv[k - i];
-        q[k] = (uint8_t)(s & 255);
-        carry = s >> 8;
+    uint8_t low[POLY_MAX_K + 1], q[POLY_MAX_K], modb[POLY_MAX_K];
+    for (int j = 0; j < d.nmod; j++) modb[j] = d.modv ? (uint8_t)row.get(d.modv[j]) : d.mod[j];
+    if (!d.modv) {
+        // the low nq digits of V, then q = low * pinv mod 256^nq
+        int64_t t = 0;
+        for (int k = 0; k < d.nq; k++) {
+            if (k < d.K) t += c[k];
+            low[k] = (uint8_t)(t & 255);
+            t = (t - low[k]) / 256;
+        }
+        uint64_t carry = 0;
+        for (int k = 0; k < d.nq; k++) {
+            uint64_t s = carry;
+            for (int i = 0; i <= k; i++) s += (uint64_t)low[i] * d.pinv[k - i];
+            q[k] = (uint8_t)(s & 255);
+            carry = s >> 8;
+        }
+    } else {
+        // a modulus from the row may be even: all K digits of V (non-negative by construction), then schoolbook
+        // division in base 256 (quotient digit by repeated subtraction: at most 255 steps of nmod bytes)
+        int64_t t = 0;
+        for (int k = 0; k < d.K; k++) {
+            t += c[k];
+            low[k] = (uint8_t)(t & 255);
+            t = (t - low[k]) / 256;
+        }
+        if (t != 0) return false;
+        int nm = d.nmod;
+        while (nm > 0 && modb[nm - 1] == 0) nm--;
+        if (nm == 0) return false;
+        uint8_t rem[POLY_MAX_K + 2] = {0};    // running remainder, little-endian, nm + 1 bytes
+        for (int k = 0; k < d.nq; k++) q[k] = 0;
+        for (int k = d.K - 1; k >= 0; k--) {
+            for (int i = nm; i > 0; i--) rem[i] = rem[i - 1];
+            rem[0] = low[k];
+            int digit = 0;
+            for (;;) {
+                bool ge = rem[nm] != 0;
+                if (!ge) {
+                    ge = true;
+                    for (int i = nm - 1; i >= 0; i--)
+                        if (rem[i] != modb[i]) { ge = rem[i] > modb[i]; break; }
+                }
+                if (!ge) break;
+                int borrow = 0;
+                for (int i = 0; i <= nm; i++) {
+                    int v = (int)rem[i] - (i < nm ? modb[i] : 0) - borrow;
+                    borrow = v < 0;
+                    rem[i] = (uint8_t)(v + (borrow << 8));
+                }
+                digit++;
+            }
+            if (digit) {
+                if (k >= d.nq || digit > 255) return false;
+                q[k] = (uint8_t)digit;
+            }
+        }
+        for (int i = 0; i <= nm; i++)
+            if (rem[i]) return false;         // V is not a multiple of the modulus
     }
     for (int k = 0; k < d.nq; k++) row.put(d.q[k], q[k]);
     for (int i = 0; i < d.nq; i++)
         if (q[i])
-            for (int j = 0; j < d.nmod; j++) c[i + j] -= (int64_t)q[i] * d.mod[j];
+            for (int j = 0; j < d.nmod; j++) c[i + j] -= (int64_t)q[i] * modb[j];
     int64_t W = 0;
     for (int k = 0; k + 1 < d.K; k++) {
         const int64_t s = c[k] + W;

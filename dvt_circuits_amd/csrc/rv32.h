@@ -49,7 +49,8 @@ constexpr uint32_t BAD_PC = 1;                // program-table target of a JAL /
 constexpr uint32_t MAX_SHARDS = 65535;        // shard numbers travel as 16-bit halves of the cycle records
 constexpr uint32_t ALU_SLL = 1, ALU_SRL = 2, ALU_SRA = 3;  // alu-bus opcodes (chips outside the cpu chip): shift chip
 constexpr uint32_t ALU_MULH = 4, ALU_MULHSU = 5, ALU_DIV = 6, ALU_DIVU = 7, ALU_REM = 8, ALU_REMU = 9;  // muldiv chip
-constexpr int N_CHIPS = 13;  // program, byte, cpu, mem_image, mem_init, shift, muldiv, sha_extend, sha_compress, fp_op, fp2_op, bls_g1, secp_k1
+constexpr int N_CHIPS = 14;  // program, byte, cpu, mem_image, mem_init, shift, muldiv, sha_extend, sha_compress, fp_op, fp2_op, bls_g1, secp_k1, u256_mul
+constexpr uint32_t SYS_UINT256_MUL = 0x0001011Du;   // x := x * y mod m, the modulus after y in memory (0 = 2^256)
 // field / curve precompiles (SP1's syscall numbers as best recalled [EXTERNAL, unverified]; tools/airgen/rv32.py)
 constexpr uint32_t SYS_SECP256K1_ADD = 0x0001010Au, SYS_SECP256K1_DOUBLE = 0x0000010Bu;
 constexpr uint32_t SYS_BLS12381_ADD = 0x0001011Eu, SYS_BLS12381_DOUBLE = 0x0000011Fu;

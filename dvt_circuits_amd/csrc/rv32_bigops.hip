@@ -3,6 +3,10 @@
 // bls12_381 / secp256k1 crates, reference crates/dkg/Cargo.toml:24-25): what a call computes (the guest machine's
 // semantics) and the rows of the four chips that prove the calls (tools/airgen/rv32.py: build_fp_op, build_fp2_op,
 // build_weierstrass).  Host code only.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -10,9 +14,8 @@
 #include "rv32.h"
 
 #if !defined(__HIP_DEVICE_COMPILE__)
-#pragma clang optimize off
+// (only the interactions of the five precompile chips are instantiated here, and those are loops: optimised as usual)
 #include "gen/air_rv32.inc"
-#pragma clang optimize on
 #include "gen/rv32_rels.h"
 
 namespace dvt {
@@ -35,6 +38,7 @@ bool bigop_info(uint32_t code, BigOpInfo *out) {
     case SYS_BLS12381_DOUBLE: *out = {RV32_CHIP_BLS_G1, 24, 0}; return true;
     case SYS_SECP256K1_ADD: *out = {RV32_CHIP_SECP_K1, 16, 16}; return true;
     case SYS_SECP256K1_DOUBLE: *out = {RV32_CHIP_SECP_K1, 16, 0}; return true;
+    case SYS_UINT256_MUL: *out = {RV32_CHIP_U256_MUL, 8, 16}; return true;
     default: return false;
     }
 }
@@ -81,8 +85,46 @@ static const char *curve_op(const MontField<N> &F, const uint32_t *p, const uint
     return nullptr;
 }
 
+// x * y mod m for 256-bit numbers (m = 0: mod 2^256): schoolbook product, then bitwise long division
+static void u256_mulmod(const uint32_t *x, const uint32_t *y, const uint32_t *m, uint32_t *r) {
+    uint32_t prod[16] = {0};
+    for (int i = 0; i < 8; i++) {
+        uint64_t carry = 0;
+        for (int j = 0; j < 8; j++) {
+            const uint64_t t = (uint64_t)x[i] * y[j] + prod[i + j] + carry;
+            prod[i + j] = (uint32_t)t;
+            carry = t >> 32;
+        }
+        prod[i + 8] = (uint32_t)carry;
+    }
+    bool zero = true;
+    for (int i = 0; i < 8; i++) zero = zero && m[i] == 0;
+    if (zero) { memcpy(r, prod, 32); return; }
+    uint32_t rem[9] = {0};
+    for (int bit = 511; bit >= 0; bit--) {
+        for (int i = 8; i > 0; i--) rem[i] = (rem[i] << 1) | (rem[i - 1] >> 31);
+        rem[0] = (rem[0] << 1) | ((prod[bit >> 5] >> (bit & 31)) & 1);
+        bool ge = rem[8] != 0;
+        if (!ge) {
+            ge = true;
+            for (int i = 7; i >= 0; i--)
+                if (rem[i] != m[i]) { ge = rem[i] > m[i]; break; }
+        }
+        if (ge) {
+            uint64_t borrow = 0;
+            for (int i = 0; i < 9; i++) {
+                const uint64_t d = (uint64_t)rem[i] - (i < 8 ? m[i] : 0) - borrow;
+                rem[i] = (uint32_t)d;
+                borrow = (d >> 32) & 1;
+            }
+        }
+    }
+    memcpy(r, rem, 32);
+}
+
 const char *bigop_compute(uint32_t code, const uint32_t *a, const uint32_t *b, uint32_t *r, uint32_t *lam) {
     switch (code) {
+    case SYS_UINT256_MUL: u256_mulmod(a, b, b + 8, r); return nullptr;
     case SYS_BLS12381_FP_ADD: case SYS_BLS12381_FP_SUB: case SYS_BLS12381_FP_MUL:
         field_op<6>(bls(), (int)(code - SYS_BLS12381_FP_ADD), a, b, r);
         return nullptr;
@@ -108,32 +150,42 @@ const char *bigop_compute(uint32_t code, const uint32_t *a, const uint32_t *b, u
 
 // ------------------------------------------------------------------ rows
 namespace {
+// one row of a chip under construction: a contiguous scratch row (the chips are up to 1245 columns wide: writing the
+// cells straight into the column-major trace would be one cache miss per cell); scattered into the trace when complete
 struct RowRef {
-    uint32_t *m; size_t n, row;
-    uint32_t get(int col) const { return m[(size_t)col * n + row]; }
-    void put(int col, uint32_t v) { m[(size_t)col * n + row] = v; }
+    uint32_t *m;
+    uint32_t get(int col) const { return m[col]; }
+    void put(int col, uint32_t v) { m[col] = v; }
     void bytes(int col0, const uint32_t *w, int nwords) {
         for (int k = 0; k < nwords; k++)
             for (int i = 0; i < 4; i++) put(col0 + 4 * k + i, (w[k] >> (8 * i)) & 0xffu);
     }
 };
+// canonical residues with plain 64-bit arithmetic: what the walker below evaluates the interaction values in (cells are
+// canonical on the host; no Montgomery conversion per cell)
+struct Cn {
+    uint32_t v;
+};
+static inline Cn operator+(Cn a, Cn b) { uint32_t s = a.v + b.v; return Cn{s >= P ? s - P : s}; }
+static inline Cn operator-(Cn a, Cn b) { return Cn{a.v >= b.v ? a.v - b.v : a.v + P - b.v}; }
+static inline Cn operator-(Cn a) { return Cn{a.v ? P - a.v : 0}; }
+static inline Cn operator*(Cn a, Cn b) { return Cn{(uint32_t)((uint64_t)a.v * b.v % P)}; }
 // walks the generated interactions of a chip on one (host) row and counts its byte-table lookups
 struct LookupCtx {
-    using T = Fp;
+    using T = Cn;
     const RowRef &r;
     const uint32_t *pubs;
     uint32_t *byte_mult;
-    static T K(uint32_t monty) { return Fp::raw(monty); }
-    static T KI(uint32_t canonical) { return Fp::from_canonical(canonical); }
-    T main(int c, int rot) const { (void)rot; return Fp::from_canonical(r.get(c)); }   // (the precompile chips' interactions read the local row only)
-    T prep(int, int) const { return Fp::zero(); }
-    T pub(int k) const { return Fp::from_canonical(pubs[k]); }
+    static T K(uint32_t monty) { return Cn{Fp::raw(monty).canonical()}; }
+    static T KI(uint32_t canonical) { return Cn{canonical}; }
+    T main(int c, int rot) const { (void)rot; return Cn{r.get(c)}; }   // (the precompile chips' interactions read the local row only)
+    T prep(int, int) const { return Cn{0}; }
+    T pub(int k) const { return Cn{pubs[k]}; }
     void interaction(int, int bus, int sign, int, const T &mult, const T *vals, int) {
         if (bus != 2 || sign < 0) return;   // bus 2 = byte (tools/airgen/rv32.py BUSES)
-        const uint32_t m = mult.canonical();
-        if (!m) return;
-        const uint32_t op = vals[0].canonical(), b = vals[2].canonical(), c = vals[3].canonical();
-        byte_mult[(size_t)(op - 1) * 65536 + (op == B_U16 ? b : (b << 8) | c)] += m;
+        if (!mult.v) return;
+        const uint32_t op = vals[0].v, b = vals[2].v, c = vals[3].v;
+        byte_mult[(size_t)(op - 1) * 65536 + (op == B_U16 ? b : (b << 8) | c)] += mult.v;
     }
 };
 
@@ -192,6 +244,11 @@ struct WCols {   // column ids of a short-Weierstrass chip
 
 bool build_bigop_traces(const std::vector<BigOpEvent> &big, uint32_t shard, HostTraces *out, uint32_t *byte_mult, std::string *err) {
     HostTraces &T = *out;
+    const auto t_begin = std::chrono::steady_clock::now();
+    struct Report {
+        std::chrono::steady_clock::time_point t0; size_t n;
+        ~Report() { if (n && getenv("DVT_TIME_BIGOPS")) fprintf(stderr, "[bigops] %zu rows in %.3f ms\n", n, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
+    } report{t_begin, big.size()};
     std::vector<const BigOpEvent *> by_chip[N_CHIPS];
     for (auto &e : big) {
         BigOpInfo bi;
@@ -199,8 +256,8 @@ bool build_bigop_traces(const std::vector<BigOpEvent> &big, uint32_t shard, Host
         by_chip[bi.chip].push_back(&e);
     }
     const uint32_t pubs[N_PUBLIC] = {0, 0, 0, shard, 0};   // (the chips read PUB_SHARD only)
-    static const int widths[N_CHIPS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, RV32_FP_OP_MAIN_W, RV32_FP2_OP_MAIN_W, RV32_BLS_G1_MAIN_W, RV32_SECP_K1_MAIN_W};
-    for (int chip : {RV32_CHIP_FP_OP, RV32_CHIP_FP2_OP, RV32_CHIP_BLS_G1, RV32_CHIP_SECP_K1}) {
+    static const int widths[N_CHIPS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, RV32_FP_OP_MAIN_W, RV32_FP2_OP_MAIN_W, RV32_BLS_G1_MAIN_W, RV32_SECP_K1_MAIN_W, RV32_U256_MUL_MAIN_W};
+    for (int chip : {RV32_CHIP_FP_OP, RV32_CHIP_FP2_OP, RV32_CHIP_BLS_G1, RV32_CHIP_SECP_K1, RV32_CHIP_U256_MUL}) {
         auto &evs = by_chip[chip];
         T.present[chip] = !evs.empty();
         T.log_n[chip] = 0;
@@ -210,9 +267,15 @@ bool build_bigop_traces(const std::vector<BigOpEvent> &big, uint32_t shard, Host
         const size_t n = (size_t)1 << lg;
         T.log_n[chip] = lg;
         T.main[chip].assign((size_t)widths[chip] * n, 0);
+        std::vector<uint32_t> scratch(widths[chip]);
         for (size_t row = 0; row < evs.size(); row++) {
             const BigOpEvent &e = *evs[row];
-            RowRef R{T.main[chip].data(), n, row};
+            std::fill(scratch.begin(), scratch.end(), 0u);
+            RowRef R{scratch.data()};
+            struct Scatter {   // the finished row goes to its place in the column-major trace when the iteration ends
+                uint32_t *dst; const uint32_t *src; size_t n, row; int w;
+                ~Scatter() { for (int c = 0; c < w; c++) if (src[c]) dst[(size_t)c * n + row] = src[c]; }
+            } scatter{T.main[chip].data(), scratch.data(), n, row, widths[chip]};
             BigOpInfo bi;
             bigop_info(e.code, &bi);
             uint32_t ptrs[2] = {e.a_ptr, e.b_ptr};
@@ -228,6 +291,26 @@ bool build_bigop_traces(const std::vector<BigOpEvent> &big, uint32_t shard, Host
                 }
                 if (!fill_lt(R, RV32_FP_OP_rlt_f_0, RV32_FP_OP_rlt_d_0, RV32_FP_OP_r_0, 48, rels_rv32::fp_op_0_mod)) { if (err) *err = "fp_op: result not reduced"; return false; }
                 if (!finish_row<air_rv32::FpOp>(R, rels_rv32::fp_op, rels_rv32::fp_op_n, pubs, byte_mult, err)) return false;
+            } else if (chip == RV32_CHIP_U256_MUL) {
+                R.put(RV32_U256_MUL_is_real, 1); R.put(RV32_U256_MUL_clk, e.clk);
+                R.bytes(RV32_U256_MUL_xp_0, &ptrs[0], 1); R.bytes(RV32_U256_MUL_yp_0, &ptrs[1], 1);
+                R.bytes(RV32_U256_MUL_x_0, e.a, 8); R.bytes(RV32_U256_MUL_y_0, e.b, 8); R.bytes(RV32_U256_MUL_m_0, e.b + 8, 8); R.bytes(RV32_U256_MUL_r_0, e.r, 8);
+                for (int k = 0; k < 16; k++) mem_meta(R, RV32_U256_MUL_my_sh_0, k, e.b_sh[k], e.b_ts[k], shard, e.clk + 2);
+                for (int k = 0; k < 8; k++) mem_meta(R, RV32_U256_MUL_mx_sh_0, k, e.a_sh[k], e.a_ts[k], shard, e.clk + 3);
+                uint8_t mb[32];
+                bool mzero = true;
+                for (int i = 0; i < 32; i++) { mb[i] = (uint8_t)(e.b[8 + i / 4] >> (8 * (i % 4))); mzero = mzero && mb[i] == 0; }
+                R.put(RV32_U256_MUL_m_zero, mzero);
+                if (!mzero) {
+                    // an inverse of one non-zero 3-byte group of m, and r < m
+                    for (int g = 0; g < 11; g++) {
+                        uint32_t mg = 0;
+                        for (int t = 0; t < 3 && 3 * g + t < 32; t++) mg |= (uint32_t)mb[3 * g + t] << (8 * t);
+                        if (mg) { R.put(RV32_U256_MUL_mz_0 + g, inv(Fp::from_canonical(mg)).canonical()); break; }
+                    }
+                    if (!fill_lt(R, RV32_U256_MUL_rlt_f_0, RV32_U256_MUL_rlt_d_0, RV32_U256_MUL_r_0, 32, mb)) { if (err) *err = "u256_mul: result not below the modulus"; return false; }
+                }
+                if (!finish_row<air_rv32::U256Mul>(R, rels_rv32::u256_mul, rels_rv32::u256_mul_n, pubs, byte_mult, err)) return false;
             } else if (chip == RV32_CHIP_FP2_OP) {
                 const int op = (int)(e.code - SYS_BLS12381_FP2_ADD);
                 R.put(RV32_FP2_OP_is_real, 1); R.put(op == 0 ? RV32_FP2_OP_is_add : op == 1 ? RV32_FP2_OP_is_sub : RV32_FP2_OP_is_mul, 1);

@@ -429,6 +429,18 @@ def check_curve_op(names, main, L, p):
     return rows, ok
 
 
+def check_u256_mul(names, main):
+    """u256_mul: r = x * y mod m, m = 0 standing for 2^256; r below the modulus"""
+    col, _ = _cols(names, main)
+    rows = col("is_real") == 1
+    ok = np.ones_like(rows)
+    val = lambda nm, r: sum(int(main[names.index(f"{nm}[{i}]"), r]) << (8 * i) for i in range(32))
+    for r in np.nonzero(rows)[0]:
+        m = val("m", r) or 1 << 256
+        ok[r] = val("r", r) == val("x", r) * val("y", r) % m and int(col("m_zero")[r]) == int(val("m", r) == 0)
+    return rows, ok
+
+
 def check_chip(name, names, main, pubs):
     """-> (rows of the statement, rows satisfying it) for the hand-written statement(s) of chip `name`, or None"""
     shard = int(pubs[3])
@@ -441,5 +453,6 @@ def check_chip(name, names, main, pubs):
         return out_rows, out_ok
     table = {"shift": check_shift, "muldiv": check_muldiv, "sha_extend": check_sha_extend, "sha_compress": check_sha_compress,
              "mem_init": check_mem_init, "fp_op": check_field_op, "fp2_op": lambda n_, m_: check_field_op(n_, m_, fp2=True),
-             "bls_g1": lambda n_, m_: check_curve_op(n_, m_, 48, BLS_P), "secp_k1": lambda n_, m_: check_curve_op(n_, m_, 32, SECP_P)}
+             "bls_g1": lambda n_, m_: check_curve_op(n_, m_, 48, BLS_P), "secp_k1": lambda n_, m_: check_curve_op(n_, m_, 32, SECP_P),
+             "u256_mul": check_u256_mul}
     return table[name](names, main) if name in table else None

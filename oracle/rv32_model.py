@@ -38,7 +38,8 @@ SECP_P = (1 << 256) - (1 << 32) - 977
 BIG_OPS = {0x00010120: ("fp_op", "add", 12, 12), 0x00010121: ("fp_op", "sub", 12, 12), 0x00010122: ("fp_op", "mul", 12, 12),
            0x00010123: ("fp2_op", "add", 24, 24), 0x00010124: ("fp2_op", "sub", 24, 24), 0x00010125: ("fp2_op", "mul", 24, 24),
            0x0001011E: ("bls_g1", "add", 24, 24), 0x0000011F: ("bls_g1", "dbl", 24, 0),
-           0x0001010A: ("secp_k1", "add", 16, 16), 0x0000010B: ("secp_k1", "dbl", 16, 0)}
+           0x0001010A: ("secp_k1", "add", 16, 16), 0x0000010B: ("secp_k1", "dbl", 16, 0),
+           0x0001011D: ("u256_mul", "mul", 8, 16)}
 
 
 def words_to_int(ws):
@@ -52,6 +53,9 @@ def int_to_words(v, n):
 def big_op(chip, op, a, b):
     """-> (result words, slope or None) of one call, or raises Trap: the guest machine's semantics of the precompiles.
     Field operands may be any 384-bit numbers (the result is reduced); curve coordinates must be reduced."""
+    if chip == "u256_mul":          # x * y mod m, the modulus behind y in memory; m = 0 stands for 2^256
+        m = words_to_int(b[8:]) or 1 << 256
+        return int_to_words(words_to_int(a) * words_to_int(b[:8]) % m, 8), None
     if chip in ("fp_op", "fp2_op"):
         f = {"add": lambda x, y: (x + y) % BLS_P, "sub": lambda x, y: (x - y) % BLS_P, "mul": lambda x, y: x * y % BLS_P}[op]
         if chip == "fp_op":
@@ -1003,7 +1007,7 @@ def traces(run: Run, pos: int):
             his.append(h)
         range_pairs(his)
 
-    for cname_ in ("fp_op", "fp2_op", "bls_g1", "secp_k1"):
+    for cname_ in ("fp_op", "fp2_op", "bls_g1", "secp_k1", "u256_mul"):
         evs = [e for e in sh["big"] if e["chip"] == cname_]
         if not evs:
             continue
@@ -1013,7 +1017,32 @@ def traces(run: Run, pos: int):
         for r_, ev in enumerate(evs):
             put, putv = _col_setter(chip, mat, r_)
             op = ev["op"]
-            put("is_real", 1); put("is_" + op, 1); put("clk", ev["clk"])
+            put("is_real", 1); put("clk", ev["clk"])
+            if cname_ == "u256_mul":
+                L = 32
+                putv("xp", byts(ev["a_ptr"])); putv("yp", byts(ev["b_ptr"]))
+                lk.add(B_ADDR, byts(ev["a_ptr"])[0], byts(ev["a_ptr"])[3]); lk.add(B_ADDR, byts(ev["b_ptr"])[0], byts(ev["b_ptr"])[3])
+                mem_cells(put, "my", ev["bprev"], ev["clk"] + 2)
+                mem_cells(put, "mx", ev["aprev"], ev["clk"] + 3)
+                xv, yv, mv, rv = words_to_int(ev["a"]), words_to_int(ev["b"][:8]), words_to_int(ev["b"][8:]), words_to_int(ev["r"])
+                putv("x", bytes_of(xv, L)); putv("y", bytes_of(yv, L)); putv("m", bytes_of(mv, L)); putv("r", bytes_of(rv, L))
+                range_pairs(bytes_of(rv, L))
+                mod = mv or 1 << 256
+                assert (xv * yv - rv) % mod == 0
+                qv = bytes_of((xv * yv - rv) // mod, L + 1)
+                putv("q", qv)
+                range_pairs(qv)
+                put("m_zero", int(mv == 0))
+                if mv:
+                    grp = lambda v, g: (v >> (24 * g)) & 0xFFFFFF
+                    g = next(g for g in range(11) if grp(mv, g))
+                    put(f"mz[{g}]", inv(grp(mv, g)))
+                    lt_cells(put, putv, "rlt", rv, mv, L)
+                M33 = bytes_of(mv, L) + [int(mv == 0)]
+                co = lin(2 * L + 1, (1, conv(bytes_of(xv, L), bytes_of(yv, L))), (-1, bytes_of(rv, L)), (-1, conv(qv, M33)))
+                carry_cells(put, "rel", rels["rel"], co)
+                continue
+            put("is_" + op, 1)
             if cname_ in ("fp_op", "fp2_op"):
                 L, p_ = 48, BLS_P
                 Pl = bytes_of(p_, L)

@@ -1179,6 +1179,8 @@ SYS_SECP256K1_ADD, SYS_SECP256K1_DOUBLE = 0x0001010A, 0x0000010B
 SYS_BLS12381_ADD, SYS_BLS12381_DOUBLE = 0x0001011E, 0x0000011F
 SYS_BLS12381_FP_ADD, SYS_BLS12381_FP_SUB, SYS_BLS12381_FP_MUL = 0x00010120, 0x00010121, 0x00010122
 SYS_BLS12381_FP2_ADD, SYS_BLS12381_FP2_SUB, SYS_BLS12381_FP2_MUL = 0x00010123, 0x00010124, 0x00010125
+SYS_UINT256_MUL = 0x0001011D
+BLS_R = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
 BLS_P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
 SECP_P = (1 << 256) - (1 << 32) - 977
 SECP_G = (0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798, 0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8)
@@ -1310,4 +1312,29 @@ def curve_ops(bad=None):
             exp += pw(pt)
         at += 4 * 2 * W * 5
     _finish(a, out, 4 * nres)
+    return a.elf(), b"".join(struct.pack("<I", v) for v in exp)
+
+
+def u256_ops(bad=None):
+    """UINT256_MUL (a0 = x, a1 = y followed by the modulus): x := x * y mod m on the BLS12-381 scalar field, on an even
+    modulus, on m = 1, on m = 0 (= 2^256, SP1's convention) and with x = y through aliasing-free copies.  Returns
+    (elf, expected result bytes).  bad = "misaligned": the call traps."""
+    top = (1 << 256) - 1
+    cases = [(3, 5, BLS_R), (BLS_R - 1, BLS_R - 1, BLS_R), (top, top, BLS_R), (top, top, 0), (0x1234 << 200, 77, 1 << 255),
+             (top - 5, 2, top), (12345, 67890, 1), (top, top, (1 << 256) - 189), (1 << 128, 1 << 128, 0), (5, 0, 7)]
+    a = Asm()
+    out = a.dword("out", [0] * (8 * len(cases) + 4))
+    exp = []
+    for n_, (x, y, m) in enumerate(cases):
+        src = a.dword(f"x{n_}", words_of(x, 8))
+        ym = a.dword(f"ym{n_}", words_of(y, 8) + words_of(m, 8))
+        at = out + 32 * n_
+        a.li("s1", src)
+        a.li("s2", at)
+        for i in range(8):
+            a.lw("a5", "s1", 4 * i)
+            a.sw("a5", "s2", 4 * i)
+        _syscall(a, SYS_UINT256_MUL, at + (2 if bad == "misaligned" and n_ == 0 else 0), ym)
+        exp += words_of(x * y % (m or 1 << 256), 8)
+    _finish(a, out, 32 * len(cases))
     return a.elf(), b"".join(struct.pack("<I", v) for v in exp)

@@ -77,7 +77,7 @@ def _encshare_case():
 
 @pytest.mark.parametrize("log_shard,which", [(21, "bignum"), (8, "bignum"), (9, "shifts"), (10, "muldiv"), (16, "encshare"),
                                              (21, "sha_extend"), (9, "sha_extend"), (21, "sha256_precompiled"), (10, "sha256_precompiled"),
-                                             (21, "field_ops"), (9, "field_ops"), (21, "curve_ops"), (8, "curve_ops"), (13, "horner")])
+                                             (21, "field_ops"), (9, "field_ops"), (21, "curve_ops"), (8, "curve_ops"), (13, "horner"), (21, "u256_ops"), (7, "u256_ops")])
 def test_rv32_proof_bytes_equal_oracle(log_shard, which):
     from dvt_circuits_amd import capi
 

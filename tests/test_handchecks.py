@@ -15,7 +15,7 @@ P = 2013265921
 
 GUESTS = {"arith": lambda: guests.arith()[0], "subword": lambda: guests.subword()[0], "shifts": lambda: guests.shifts()[0],
           "muldiv": lambda: guests.muldiv()[0], "sha": lambda: guests.sha256_precompiled(bytes(range(70)))[0],
-          "field": lambda: guests.field_ops()[0], "curve": lambda: guests.curve_ops()[0]}
+          "field": lambda: guests.field_ops()[0], "curve": lambda: guests.curve_ops()[0], "u256": lambda: guests.u256_ops()[0]}
 # chip -> (guest, result cells whose change the statement must notice)
 CASES = {
     "cpu": ("subword", ["a[0]", "a[3]", "u[9]", "u[12]", "next_pc"]),
@@ -28,6 +28,7 @@ CASES = {
     "fp2_op": ("field", ["r0[5]", "r1[40]"]),
     "bls_g1": ("curve", ["x3[0]", "y3[47]"]),
     "secp_k1": ("curve", ["x3[31]", "y3[0]"]),
+    "u256_mul": ("u256", ["r[0]", "r[31]", "m_zero"]),
 }
 
 

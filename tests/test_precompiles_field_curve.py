@@ -48,21 +48,24 @@ def test_python_curve_helpers_reproduce_known_multiples():
     assert (guests.SECP_G[1] ** 2 - guests.SECP_G[0] ** 3 - 7) % guests.SECP_P == 0
 
 
-@pytest.mark.parametrize("which,log_shard", [("field", 0), ("field", 9), ("curve", 0), ("curve", 8)])
+GUESTS = {"field": guests.field_ops, "curve": guests.curve_ops, "u256": guests.u256_ops}
+
+
+@pytest.mark.parametrize("which,log_shard", [("field", 0), ("field", 9), ("curve", 0), ("curve", 8), ("u256", 0), ("u256", 7)])
 def test_guest_runs_and_every_shard_satisfies_the_air(air, which, log_shard):
-    elf, want = (guests.field_ops if which == "field" else guests.curve_ops)()
+    elf, want = GUESTS[which]()
     rc, rep, pv, out, err = capi.execute_io(elf)
     assert rc == 0 and rep["halted"] and not rep["unprovable"], err
     assert out == want and pv == guests.checksum(want)
     chips, pubs = check_traces(air, elf, log_shard=log_shard)
     if log_shard == 0:
         present = {air.chip(c["chip_id"]).name.decode() for c in chips}
-        assert ({"fp_op", "fp2_op"} if which == "field" else {"bls_g1", "secp_k1"}) <= present
+        assert {"field": {"fp_op", "fp2_op"}, "curve": {"bls_g1", "secp_k1"}, "u256": {"u256_mul"}}[which] <= present
 
 
-@pytest.mark.parametrize("which,log_shard", [("field", 21), ("field", 9), ("curve", 21), ("curve", 8)])
+@pytest.mark.parametrize("which,log_shard", [("field", 21), ("field", 9), ("curve", 21), ("curve", 8), ("u256", 21), ("u256", 7)])
 def test_product_rows_equal_the_independent_model(which, log_shard):
-    elf, want = (guests.field_ops if which == "field" else guests.curve_ops)()
+    elf, want = GUESTS[which]()
     run = rv32_model.Run(elf, (), log_shard)
     rc, rep, pv, out, err = capi.execute_io(elf)
     assert rc == 0 and run.error == "" and run.halted, (err, run.error)
@@ -85,6 +88,8 @@ def test_invalid_calls_trap():
         rc, rep, _, err = capi.execute(guests.field_ops(bad=bad)[0])
         assert rc == capi.DVT_ERR_GUEST and frag in err, (bad, err)
         assert frag in rv32_model.Run(guests.field_ops(bad=bad)[0]).error
+    rc, rep, _, err = capi.execute(guests.u256_ops(bad="misaligned")[0])
+    assert rc == capi.DVT_ERR_GUEST and "misaligned" in err
     for bad, frag in (("equal", "equal abscissae"), ("unreduced", "not reduced"), ("a1", "a1 != 0")):
         rc, rep, _, err = capi.execute(guests.curve_ops(bad=bad)[0])
         assert rc == capi.DVT_ERR_GUEST and frag in err, (bad, err)
@@ -111,12 +116,12 @@ def _free_cells(air, chips, pubs, extra, chip, names, row):
     return free
 
 
-@pytest.mark.parametrize("chip_name,guest", [("fp_op", "field"), ("fp2_op", "field"), ("bls_g1", "curve"), ("secp_k1", "curve")])
+@pytest.mark.parametrize("chip_name,guest", [("fp_op", "field"), ("fp2_op", "field"), ("bls_g1", "curve"), ("secp_k1", "curve"), ("u256_mul", "u256")])
 def test_every_cell_of_a_row_is_pinned(air, chip_name, guest):
     """single-cell changes on one row per operation of the chip: every one breaks a constraint or the LogUp balance,
     except cells the operation does not read (the second operand and its access columns on DOUBLE rows, the inequality
     witnesses of the groups that are not used)"""
-    elf, want = (guests.field_ops if guest == "field" else guests.curve_ops)()
+    elf, want = GUESTS[guest]()
     chips, pubs, _ = capi.rv32_debug_traces(elf)
     extra = pv_extra(guests.checksum(want))
     assert air.logup_unbalanced(chips, pubs, extra=extra)[0] == 0
@@ -124,6 +129,16 @@ def test_every_cell_of_a_row_is_pinned(air, chip_name, guest):
     names = _names(chip_name.upper())
     col = {n: i for i, n in names.items()}
     main = chip["main"]
+    if chip_name == "u256_mul":
+        # an odd modulus, the modulus 0 (= 2^256) and an even one: every cell pinned but the inverse witnesses of m's groups
+        # (any solution of sum m_g z_g = 1 will do) and, for m = 0, the comparison witnesses nothing reads
+        for row in (0, 3, 4):
+            free = _free_cells(air, chips, pubs, extra, chip, names, row)
+            allowed = {n for n in names.values() if n.startswith("mz_")}
+            if main[col["m_zero"], row] == 1:
+                allowed |= {n for n in names.values() if n.startswith("rlt_")}
+            assert free <= allowed, (row, sorted(free - allowed)[:20])
+        return
     ops = ["is_add", "is_sub", "is_mul"] if chip_name.startswith("fp") else ["is_add", "is_dbl"]
     for op in ops:
         row = next(r for r in range(main.shape[1]) if main[col[op], r] == 1)

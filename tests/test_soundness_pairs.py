@@ -203,11 +203,13 @@ def test_sha_chip_pairs(air, machine, chip_name):
     assert not esc, esc[:10]
 
 
-@pytest.mark.parametrize("chip_name,guest", [("fp_op", "field_ops"), ("fp2_op", "field_ops"), ("bls_g1", "curve_ops"), ("secp_k1", "curve_ops")])
+@pytest.mark.parametrize("chip_name,guest", [("fp_op", "field_ops"), ("fp2_op", "field_ops"), ("bls_g1", "curve_ops"), ("secp_k1", "curve_ops"),
+                                             ("u256_mul", "u256_ops")])
 def test_precompile_chip_pairs(air, machine, chip_name, guest):
     chips, pubs = _traces(getattr(guests, guest)()[0])
     # the inequality witness of ADD: sum_g (x1_g - x2_g) z_g = 1 — two z cells of groups that differ can trade value
     nz = 16 if chip_name == "bls_g1" else 11
     allowed = {(f"xne_z[{i}]", f"xne_z[{j}]") for i in range(nz) for j in range(nz)}
+    allowed |= {(f"mz[{i}]", f"mz[{j}]") for i in range(11) for j in range(11)}       # u256_mul: sum_g m_g z_g = 1 likewise
     esc = _hunt(air, machine, chips, pubs, chip_name, np.random.default_rng(14), allowed)
     assert not esc, esc[:10]

@@ -494,10 +494,15 @@ def emit_rels_header(machine):
             out += rows
             out.append("};")
             nq = len(rel.q)
-            pinv = pow(sum(b << (8 * i) for i, b in enumerate(rel.modulus)), -1, 1 << (8 * nq))
             out.append(f"static const int16_t {pre}_q[] = {{{', '.join(str(col_of(x)) for x in rel.q)}}};")
-            out.append(f"static const uint8_t {pre}_mod[] = {{{', '.join(str(x) for x in rel.modulus)}}};")
-            out.append(f"static const uint8_t {pre}_pinv[] = {{{', '.join(str((pinv >> (8 * i)) & 0xFF) for i in range(nq))}}};")
+            if all(isinstance(b, int) for b in rel.modulus):
+                pinv = pow(sum(b << (8 * i) for i, b in enumerate(rel.modulus)), -1, 1 << (8 * nq))
+                out.append(f"static const uint8_t {pre}_mod[] = {{{', '.join(str(x) for x in rel.modulus)}}};")
+                out.append(f"static const uint8_t {pre}_pinv[] = {{{', '.join(str((pinv >> (8 * i)) & 0xFF) for i in range(nq))}}};")
+                out.append(f"static const int16_t *const {pre}_modv = nullptr;")
+            else:       # the modulus is read from the row (UINT256_MUL): the solver divides
+                out.append(f"static const uint8_t *const {pre}_mod = nullptr, *const {pre}_pinv = nullptr;")
+                out.append(f"static const int16_t {pre}_modv[] = {{{', '.join(str(col_of(x)) for x in rel.modulus)}}};")
             out.append(f"static const int16_t {pre}_w[] = {{{', '.join(str(col_of(x)) for x in rel.w_lo)}}};")
             if rel.w_top:
                 out.append(f"static const int16_t {pre}_wb[] = {{{', '.join(str(col_of(x)) for x in rel.w_top)}}};")
@@ -506,7 +511,7 @@ def emit_rels_header(machine):
         for ri, rel in enumerate(rels):
             pre = f"{cu}_{ri}"
             wb = f"{pre}_wb" if rel.w_top else "nullptr"
-            out.append(f'    {{"{rel.name}", {len(rel.terms) - 1}, {pre}_terms, {rel.K}, {pre}_q, {len(rel.q)}, {pre}_mod, {len(rel.modulus)}, {pre}_pinv, {pre}_w, {wb}, {pre}_woff}},')
+            out.append(f'    {{"{rel.name}", {len(rel.terms) - 1}, {pre}_terms, {rel.K}, {pre}_q, {len(rel.q)}, {pre}_mod, {len(rel.modulus)}, {pre}_pinv, {pre}_w, {wb}, {pre}_woff, {pre}_modv}},')
         out.append("};")
         out.append(f"constexpr int {cu}_n = {len(rels)};")
         out.append("")

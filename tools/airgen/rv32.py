@@ -18,6 +18,7 @@ Chips
   fp2_op    BLS12-381 Fp2 add / sub / mul precompiles (one row per call)
   bls_g1    BLS12-381 G1 affine add / double precompiles (one row per call)
   secp_k1   secp256k1 affine add / double precompiles (one row per call; the same short-Weierstrass a = 0 template)
+  u256_mul  UINT256_MUL precompile: x := x * y mod m for 256-bit numbers, the modulus read from memory (one row per call)
 
 Memory consistency is an offline-checking LogUp multiset over tuples
 (addr, byte0..3, timestamp): every access consumes the previous tuple of its
@@ -56,6 +57,7 @@ REG_A1 = 11
 # sp1-core-executor crate is absent]; byte 1 = 1 "has a table" is what the cpu chip keys on, the chips receive the full code
 SYS_SECP256K1_ADD, SYS_SECP256K1_DOUBLE = 0x0001010A, 0x0000010B
 SYS_BLS12381_ADD, SYS_BLS12381_DOUBLE = 0x0001011E, 0x0000011F
+SYS_UINT256_MUL = 0x0001011D
 SYS_BLS12381_FP_ADD, SYS_BLS12381_FP_SUB, SYS_BLS12381_FP_MUL = 0x00010120, 0x00010121, 0x00010122
 SYS_BLS12381_FP2_ADD, SYS_BLS12381_FP2_SUB, SYS_BLS12381_FP2_MUL = 0x00010123, 0x00010124, 0x00010125
 BLS12381_P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
@@ -1040,6 +1042,61 @@ def build_secp_k1():
     return build_weierstrass("secp_k1", 32, SECP256K1_P, SYS_SECP256K1_ADD, SYS_SECP256K1_DOUBLE)
 
 
+def assert_lt_vec(ch, name, vec, bound, sel):
+    """vec < bound as integers (both range-checked byte vectors of one length; bound is made of columns), where sel = 1:
+    the variable-bound form of assert_lt_const"""
+    gv, gb = groups3(vec), groups3(bound)
+    G = len(gv)
+    f = ch.cols(name + "_f", G)
+    d = ch.cols(name + "_d", 3)
+    for x in f:
+        ch.assert_zero(x * (x - 1))
+    ch.assert_eq(esum(f), sel)
+    for g in range(G):
+        ch.assert_zero((sel - esum(f[g:])) * (gv[g] - gb[g]))
+    ch.assert_zero(esum(f[g] * (gb[g] - gv[g] - 1) for g in range(G)) - (d[0] + 256 * d[1] + 65536 * d[2]))
+    ch.send("byte", [B_RANGE, 0, d[0], d[1]], sel)
+    ch.send("byte", [B_RANGE, 0, d[2], 0], sel)
+
+
+def build_u256_mul():
+    """UINT256_MUL (a0 = x: 8 little-endian words; a1 = y: 8 words followed by the 8 words of the modulus m):
+    x := x * y mod m, with m = 0 standing for 2^256 (SP1's convention; what the patched bls12_381 crate's scalar field
+    arithmetic calls).  x * y - r - q * M = 0 as one big-integer identity with the VARIABLE modulus M = m + is_zero * 2^256;
+    the result is below M."""
+    L = 32
+    ch = Chip("u256_mul")
+    shard = ch.pub(PUB_SHARD)
+    is_real, m_zero, clk = ch.col("is_real"), ch.col("m_zero"), ch.col("clk")
+    xp, yp = ch.cols("xp", 4), ch.cols("yp", 4)
+    x, y, m, r, q = ch.cols("x", L), ch.cols("y", L), ch.cols("m", L), ch.cols("r", L), ch.cols("q", L + 1)
+    mz = ch.cols("mz", (L + 2) // 3)
+    ch.assert_bool(is_real)
+    ch.assert_bool(m_zero)
+    ch.assert_zero(m_zero * (1 - is_real))
+    ch.assert_zero(is_real.next() * (1 - is_real), "trans")
+    ch.receive("sys", code_bytes([(is_real, SYS_UINT256_MUL)]) + xp + yp + [clk, shard], is_real)
+    ch.send("byte", [B_ADDR, 0, xp[0], xp[3]], is_real)
+    ch.send("byte", [B_ADDR, 0, yp[0], yp[3]], is_real)
+    mem_words(ch, "my", yp, y + m, y + m, shard, clk + 2, is_real)
+    mem_words(ch, "mx", xp, x, r, shard, clk + 3, is_real)
+    range_bytes(ch, r, is_real)
+    range_bytes(ch, q, is_real)
+    # m_zero = 1 exactly when m = 0:  m_zero * m_i = 0,  sum_g m_g z_g = is_real - m_zero (an inverse of one non-zero group)
+    for i in range(L):
+        ch.assert_zero(m_zero * m[i])
+    gm = groups3(m)
+    ch.assert_zero(esum(gm[g] * mz[g] for g in range(len(gm))) - (is_real - m_zero))
+    assert_lt_vec(ch, "rlt", r, m, is_real - m_zero)
+    M = m + [m_zero]                                      # the modulus as L + 1 limbs: m, or 2^256 when m = 0
+    w = ch.assert_poly_zero("rel", [(1, is_real, x, y), (-1, is_real, r, None)], q, M, is_real, [{is_real.id: 1}])
+    for t in w:
+        ch.send("byte", [B_U16, 0, t, 0], is_real)
+    ch.quotient_parts = 1
+    ch.logup_parts = 2
+    return ch
+
+
 def build_mem_image():
     ch = Chip("mem_image")
     addr, v, real = ch.prep("addr"), ch.preps("v", 4), ch.prep("is_real")
@@ -1084,4 +1141,4 @@ def build_mem_init():
 
 def build():
     return Machine("rv32", [build_program(), build_byte(), build_cpu(), build_mem_image(), build_mem_init(), build_shift(), build_muldiv(),
-                            build_sha_extend(), build_sha_compress(), build_fp_op(), build_fp2_op(), build_bls_g1(), build_secp_k1()], BUSES)
+                            build_sha_extend(), build_sha_compress(), build_fp_op(), build_fp2_op(), build_bls_g1(), build_secp_k1(), build_u256_mul()], BUSES)
