@@ -258,3 +258,32 @@ def test_reference_horner_kat_is_proven_through_the_curve_precompiles(gpu):
     w[4] ^= 1
     assert not capi.verify(vk, w.tobytes(), Q, POW)[0]
     gpu.pk_free(pk)
+
+
+def test_reference_finalization_example_is_proven_with_the_reference_public_values(gpu):
+    """BASELINE configs[1]: finalization_prove on examples/finalization_test.json.  The re-stated guest
+    (tests/guests_finalization.py: everything of crates/finalization_prove/src/main.rs but the pairings) is executed AND
+    proven on the reference's own example input; the proof verifies and its public values are the bytes the reference
+    commits (main.rs:26-32)."""
+    import json
+    import os
+
+    from dvt_circuits_amd import capi
+    from tests import guests_finalization as gf
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    example = open(os.path.join(root, "tests", "golden", "finalization_example.json"), "rb").read()
+    buf = capi.stdin_from_json("finalization", example)
+    elf = gf.finalization(nmax=8, kmax=8)
+    pk, vk = gpu.setup(elf)
+    proof, rep = gpu.prove_core(pk, [buf])
+    ok, ec, pv, why = capi.verify(vk, proof, Q, POW)
+    assert ok and ec == 0, why
+    assert pv == gf.expected_public_values(json.loads(example)) and len(pv) == 320
+    # a vector the reference expects to FAIL (wrong aggregate key) cannot be proven: the guest halts with exit code 1
+    vec = json.load(open(os.path.join(root, "tests", "golden", "finalization_vectors", "report-1-wrong-aggregate-pubkey.json")))
+    bad = capi.stdin_from_json("finalization", json.dumps(vec["scenario"]).encode())
+    with pytest.raises(capi.DvtError) as e:
+        gpu.prove_core(pk, [bad])
+    assert e.value.code == capi.DVT_ERR_GUEST
+    gpu.pk_free(pk)
