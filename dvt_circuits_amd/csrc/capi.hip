@@ -515,9 +515,15 @@ static int shard_traces(dvt_prover *p, const dvt_pk *pk, dvt_job *j, ShardJob &s
 // phase 1 of a shard: K0 + K1..K3 of the main traces -> header
 static int shard_commit(dvt_prover *p, const dvt_pk *pk, dvt_job *j, ShardJob &s) {
     std::vector<ChipTrace> traces;
+    const bool time_stages = getenv("DVT_TIME_PREPARE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (time_stages) fprintf(stderr, "[commit] %s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    };
     // keep the phase-1 results in HBM while they fit (about 3 GB per 2^21-cycle shard); otherwise phase 2 recomputes
     size_t free_b = 0, total_b = 0;
     if (p->keep_phase1 && !s.cache.tree) { (void)hipMemGetInfo(&free_b, &total_b); free_b += p->eng.pool.cached_bytes; }   // (only the first commit of a shard asks)
+    lap("memory asked");
     MainCache *keep = p->keep_phase1 && (s.cache.tree || free_b > ((size_t)24 << 30)) ? &s.cache : nullptr;
     if (keep && !s.d_cpu) {
         DevPool &pool = p->eng.pool;
@@ -528,10 +534,13 @@ static int shard_commit(dvt_prover *p, const dvt_pk *pk, dvt_job *j, ShardJob &s
             for (uint32_t **d : {&s.d_cpu, &s.d_byte, &s.d_prog}) { pool.free(*d); *d = nullptr; }
         }
     }
+    lap("trace buffers");
     int rc = shard_traces(p, pk, j, s, &traces, false);
     if (rc) return rc;
+    lap("K0 launched");
     Digest root;
     if (!p->eng.commit_main_root(pk->key, traces, &root, keep)) return fail(p, DVT_ERR_DEVICE, "%s", p->eng.err.c_str());
+    lap("main root");
     for (int k = 0; k < 8; k++) s.header[k] = root.d[k].canonical();
     for (uint32_t k = 0; k < N_PUB; k++) s.header[8 + k] = s.pubs[k].canonical();
     s.header_valid = true;
@@ -567,6 +576,7 @@ struct ReadyShard {
     rv32::CycleRec *buf = nullptr;
     rv32::ShardMeta meta{};
     rv32::HostTraces aux;
+    rv32::BigOpBatches big;   // the precompile calls of the shard: their chips' rows are built on the GPU
     std::string err;
     bool unsupported = false;
 };
@@ -609,6 +619,9 @@ static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_buf
     }
     Pipeline pl;
     pl.free_bufs = p->pinned;
+    const bool time_stages = getenv("DVT_TIME_PREPARE") != nullptr;   // (stderr: where the host side of a prepare goes)
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since_begin = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
 
     std::thread fast([&] {
         rv32::Vm vm(prog, &inputs, log_shard);
@@ -660,12 +673,14 @@ static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_buf
                 }
                 ReadyShard r;
                 r.buf = buf;
+                const auto tw0 = std::chrono::steady_clock::now();
                 {
                     rv32::Vm vm(prog, &inputs, log_shard, snap);
                     snap = rv32::Snapshot();
                     rv32::ShardOut so;
                     so.recs = buf;
                     vm.run_shard(true, &so, max_cycles);
+                    const auto tw1 = std::chrono::steady_clock::now();
                     r.meta = rv32::ShardMeta{so.index, so.start_pc, so.next_pc, so.n_recs};
                     if (!vm.error.empty()) { r.err = vm.error; r.unsupported = vm.unsupported; }
                     else {
@@ -678,7 +693,13 @@ static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_buf
                             ec = pl.exit_code;
                         }
                         std::string e;
-                        if (!pl.abort && !rv32::build_aux_host(r.meta, so.alu, so.sha_ext, so.sha_cmp, so.big, rows, ec, pk->prep, &r.aux, &e)) r.err = e;
+                        const auto tw2 = std::chrono::steady_clock::now();
+                        if (!pl.abort && !rv32::build_aux_host(r.meta, so.alu, so.sha_ext, so.sha_cmp, so.big, rows, ec, pk->prep, &r.aux, &e, &r.big)) r.err = e;
+                        if (time_stages) {
+                            auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+                            fprintf(stderr, "[prepare] shard %u: traced execution %.2f ms, wait for the fast pass %.2f ms, auxiliary traces %.2f ms\n", so.index, ms(tw0, tw1), ms(tw1, tw2),
+                                    ms(tw2, std::chrono::steady_clock::now()));
+                        }
                     }
                 }
                 std::lock_guard<std::mutex> lk(pl.mu);
@@ -710,15 +731,41 @@ static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_buf
         HIP_TRY(p, p->eng.pool.alloc(&s.d_recs, s.n_recs * sizeof(rv32::CycleRec)));
         HIP_TRY(p, hipMemcpyAsync(s.d_recs, r.buf, s.n_recs * sizeof(rv32::CycleRec), hipMemcpyHostToDevice, p->copy_stream));
         HIP_TRY(p, hipEventRecord(ev, p->copy_stream));
+        uint32_t *d_calls[rv32::N_CHIPS] = {};   // per precompile chip: [error word, padding to 16 bytes, the calls]
         for (int c = 0; c < m->n_chips; c++) {
             if (c == RV32_CHIP_CPU || !s.present[c]) continue;
+            const std::vector<rv32::BigOpEvent> &calls = r.big.ev[c];
+            if (!calls.empty()) {   // a field / curve precompile chip: K0 of its rows from the calls (after the byte counts are in)
+                const size_t words = (size_t)m->chips[c].main_w << s.log_n[c];
+                HIP_TRY(p, p->eng.pool.alloc(&s.d_aux[c], words * 4));
+                HIP_TRY(p, hipMemsetAsync(s.d_aux[c], 0, words * 4, p->eng.stream));
+                HIP_TRY(p, p->eng.pool.alloc(&d_calls[c], 16 + calls.size() * sizeof(rv32::BigOpEvent)));
+                HIP_TRY(p, hipMemsetAsync(d_calls[c], 0, 16, p->eng.stream));
+                HIP_TRY(p, hipMemcpyAsync(d_calls[c] + 4, calls.data(), calls.size() * sizeof(rv32::BigOpEvent), hipMemcpyHostToDevice, p->eng.stream));
+                continue;
+            }
             size_t words = r.aux.main[c].size();
             HIP_TRY(p, p->eng.pool.alloc(&s.d_aux[c], words * 4));
             HIP_TRY(p, hipMemcpyAsync(s.d_aux[c], r.aux.main[c].data(), words * 4, hipMemcpyHostToDevice, p->eng.stream));
             // byte / program multiplicities stay plain integers until K0 has added the cpu rows' lookups
             if (c != RV32_CHIP_BYTE && c != RV32_CHIP_PROGRAM) HIP_TRY(p, launch_to_internal(p->eng.stream, s.d_aux[c], words));
         }
+        for (int c = 0; c < m->n_chips; c++) {
+            if (!d_calls[c]) continue;
+            const size_t words = (size_t)m->chips[c].main_w << s.log_n[c];
+            HIP_TRY(p, rv32::launch_k0_bigop_rows(p->eng.stream, c, reinterpret_cast<const rv32::BigOpEvent *>(d_calls[c] + 4), (uint32_t)r.big.ev[c].size(), s.index,
+                                                  s.d_aux[c], s.log_n[c], s.d_aux[RV32_CHIP_BYTE], d_calls[c]));
+            HIP_TRY(p, launch_to_internal(p->eng.stream, s.d_aux[c], words));
+        }
         HIP_TRY(p, hipStreamSynchronize(p->eng.stream));   // r.aux is pageable and about to be released
+        for (int c = 0; c < m->n_chips; c++) {
+            if (!d_calls[c]) continue;
+            uint32_t row_err = 0;
+            const hipError_t e = hipMemcpy(&row_err, d_calls[c], 4, hipMemcpyDeviceToHost);
+            p->eng.pool.free(d_calls[c]);
+            HIP_TRY(p, e);
+            if (row_err) return fail(p, DVT_ERR_DEVICE, "K0 of chip %s: %s", m->chips[c].name, rv32::bigop_row_error_text(row_err));
+        }
         for (auto x : r.aux.pubs) s.pubs.push_back(Fp::from_canonical(x));
         return DVT_OK;
     };
@@ -742,7 +789,9 @@ static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_buf
                 give_back(r.buf);
                 break;
             }
+            if (time_stages && got) fprintf(stderr, "[prepare] %.2f ms: shard at position %zu ready\n", since_begin(), pos);
             if (got) rc = upload(r);
+            if (time_stages && got) fprintf(stderr, "[prepare] %.2f ms: uploaded\n", since_begin());
             // phase 1 of the previous shard runs while the copy engine brings this one in
             if (rc == DVT_OK && have_prev) {
                 ShardJob &ps = j->shards[j->shards.size() - (got ? 2 : 1)];
@@ -763,6 +812,7 @@ static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_buf
             rc = shard_commit(p, pk, j, j->shards.back());
             give_back(prev_buf);
         }
+        if (time_stages) fprintf(stderr, "[prepare] %.2f ms: phase 1 of the last shard done\n", since_begin());
     }
     {
         std::lock_guard<std::mutex> lk(pl.mu);
@@ -772,6 +822,7 @@ static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_buf
     fast.join();
     for (auto &w : workers) w.join();
     (void)hipEventDestroy(ev);
+    if (time_stages) fprintf(stderr, "[prepare] %.2f ms: threads joined\n", since_begin());
     if (report) {
         report->cycles = pl.cycles;
         report->exit_code = pl.halted ? pl.exit_code : -1;

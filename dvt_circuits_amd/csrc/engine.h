@@ -197,6 +197,9 @@ class Engine {
     DevPool pool;
     // K5 selector tables, one per trace height this prover has seen ([3][2N] words each, stark.cuh QuotientArgs::sel)
     uint32_t *sel_tables[32] = {};
+    // row digests of the shorter matrices of the tree being committed (commit_tree): reused tree after tree on the one stream
+    uint32_t *inject_buf = nullptr;
+    size_t inject_words = 0;
     const uint32_t *selector_table(const QuotientArgs &qa);
 
   private:

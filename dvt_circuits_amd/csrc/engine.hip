@@ -85,6 +85,8 @@ void Engine::shutdown() {
     pool.trim();
     ntt_tables_destroy(&tabs);
     for (auto &t : sel_tables) { if (t) (void)hipFree(t); t = nullptr; }
+    if (inject_buf) (void)hipFree(inject_buf);
+    inject_buf = nullptr; inject_words = 0;
     if (d_ring) (void)hipFree(d_ring);
     if (h_ring) (void)hipHostFree(h_ring);
     if (h_down) (void)hipHostFree(h_down);
@@ -141,36 +143,51 @@ const uint32_t *Engine::selector_table(const QuotientArgs &qa) {
 bool Engine::commit_tree(const std::vector<DevMat> &mats, uint32_t *d_digests) {
     uint32_t mx = 0;
     for (auto &m : mats) mx = std::max(mx, m.log_h);
-    uint32_t *prev = nullptr;
-    MerkleTopInject inj;
-    bool in_top = false;
-    uint32_t top_start = 0;
-    uint32_t *top_layer = nullptr;
+    if (mx >= MERKLE_MAX_SEGMENTS) return fail("commit: tree too tall");
+    // every row sponge of the tree in one launch: the leaves and the row digests of the shorter matrices (joined to the
+    // tree at the level of their height)
+    MerkleLeafSegments sg;
+    std::vector<const uint32_t *> inject(mx + 1, nullptr);
+    size_t want = 0;
+    for (uint32_t lh = 0; lh < mx; lh++)
+        for (auto &m : mats)
+            if (m.log_h == lh) { want += (size_t)8 << lh; break; }
+    if (want > inject_words) {
+        HIPCHK(hipStreamSynchronize(stream));   // (an earlier tree's level kernels may still read the old buffer)
+        if (inject_buf) HIPCHK(hipFree(inject_buf));
+        inject_buf = nullptr; inject_words = 0;
+        HIPCHK(hipMalloc(&inject_buf, want * 4));
+        inject_words = want;
+    }
+    size_t at = 0;
     for (uint32_t lh = mx + 1; lh-- > 0;) {
         std::vector<uint64_t> ptrs;
         for (auto &m : mats)
             if (m.log_h == lh)
                 for (uint32_t c = 0; c < m.width; c++) ptrs.push_back((uint64_t)(uintptr_t)(m.ptr + ((size_t)c << lh)));
-        const uint32_t *const *d_cols = nullptr;
-        if (!ptrs.empty()) {
-            d_cols = reinterpret_cast<const uint32_t *const *>(upload(ptrs.data(), ptrs.size() * 8));
-            if (!d_cols) return false;
+        if (ptrs.empty()) continue;
+        auto d_cols = reinterpret_cast<const uint32_t *const *>(upload(ptrs.data(), ptrs.size() * 8));
+        if (!d_cols) return false;
+        uint32_t *out = d_digests;
+        if (lh != mx) {
+            out = inject_buf + at;
+            at += (size_t)8 << lh;
+            inject[lh] = out;
         }
-        if (lh == mx) {
-            HIPCHK(launch_merkle_leaves(stream, d_cols, (uint32_t)ptrs.size(), lh, d_digests));
-            prev = d_digests;
-            if (lh <= MERKLE_TOP_LOG) { in_top = true; top_start = lh; top_layer = prev; }
-        } else if (in_top) {
-            inj.cols[lh] = d_cols;
-            inj.ncols[lh] = (uint32_t)ptrs.size();
-        } else {
-            uint32_t *cur = prev + ((size_t)16 << lh);
-            HIPCHK(launch_merkle_level(stream, prev, d_cols, (uint32_t)ptrs.size(), lh, cur));
-            prev = cur;
-            if (lh <= MERKLE_TOP_LOG) { in_top = true; top_start = lh; top_layer = prev; }
-        }
+        sg.add(d_cols, (uint32_t)ptrs.size(), lh, out);
     }
-    if (in_top) HIPCHK(launch_merkle_top(stream, top_layer, top_start, inj));
+    HIPCHK(launch_merkle_leaves(stream, sg));
+    uint32_t *prev = d_digests;
+    uint32_t lh = mx;
+    while (lh > MERKLE_TOP_LOG) {
+        lh--;
+        uint32_t *cur = prev + ((size_t)16 << lh);
+        HIPCHK(launch_merkle_level(stream, prev, inject[lh], lh, cur));
+        prev = cur;
+    }
+    MerkleTopInject inj;
+    for (uint32_t l = 0; l < lh; l++) inj.digests[l] = inject[l];
+    HIPCHK(launch_merkle_top(stream, prev, lh, inj));
     return true;
 }
 
@@ -180,7 +197,7 @@ bool Engine::commit_tree_levels(uint32_t *d_digests, uint32_t log_h) {
     while (lh > MERKLE_TOP_LOG) {
         lh--;
         uint32_t *cur = prev + ((size_t)16 << lh);
-        HIPCHK(launch_merkle_level(stream, prev, nullptr, 0, lh, cur));
+        HIPCHK(launch_merkle_level(stream, prev, nullptr, lh, cur));
         prev = cur;
     }
     HIPCHK(launch_merkle_top(stream, prev, lh, MerkleTopInject()));
@@ -462,6 +479,7 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
     need += 3 * tree_words(hmax) * 4;
     need += ((size_t)1 << hmax) * 16 * 4 + 2 * tree_words(hmax) * 4;
     need += ((size_t)1 << max_log_n) * 16 * 3 + (64u << 20);
+    need += ((size_t)PARTS_MAX * 32) << std::min(max_log_n, PARTS_PARALLEL_LOG);
     if (arena.cap < need && arena.reserve(need + need / 8) != hipSuccess) { (void)hipGetLastError(); pool.trim(); HIPCHK(arena.reserve(need + need / 8)); }
 #define ALLOC(var, T, count)                                                        \
     do {                                                                            \
@@ -540,6 +558,9 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
     mats.clear();
     uint32_t perm_hmax = 0;
     size_t n_cumsum = 0;
+    // scratch of the part-parallel K4 / K5 launches of short tables (stark.cuh): [PARTS_MAX][8][rows]
+    uint32_t *d_parts;
+    ALLOC(d_parts, uint32_t, (size_t)PARTS_MAX * 8 << std::min(max_log_n, PARTS_PARALLEL_LOG));
     for (auto &s : cs) {
         if (!s.d->perm_ext_w) continue;
         const size_t bw = 4 * (size_t)s.d->perm_ext_w;
@@ -548,6 +569,7 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
         uint32_t *totals, *scan_scratch;
         ALLOC(totals, uint32_t, 4 * s.n);
         PermArgs pa{s.main, s.prep, d_pub, s.perm, totals, d_beta, d_beta_f64, perm_alpha, s.log_n};
+        if (s.log_n <= PARTS_PARALLEL_LOG) pa.partial = d_parts;
         HIPCHK(s.d->launch_perm(stream, pa));
         ALLOC(scan_scratch, uint32_t, prefix_sum_scratch_words(4, s.n));
         HIPCHK(launch_prefix_sum_columns(stream, totals, 4, s.n, scan_scratch));
@@ -605,6 +627,7 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
         qa.log_n = s.log_n;
         qa.tabs = tabs;
         qa.sel = selector_table(qa);
+        if (s.log_n <= PARTS_PARALLEL_LOG) qa.partial = d_parts;
         HIPCHK(s.d->launch_quotient(stream, qa));
         HIPCHK(lde(s.quot, d_scratch, s.quot_lde, 4, s.log_n, 1));
         HIPCHK(lde(s.quot + 4 * s.n, d_scratch, s.quot_lde + 8 * s.n, 4, s.log_n, 2));

@@ -232,18 +232,40 @@ __global__ void __launch_bounds__(256) reduced_opening_kernel(ReducedArgs a) {
     // s = sum_c alpha^c * col_c[i] in F_p^4: four exact FP64 dot products (DotAcc above); alpha^c is wave-uniform
     DotAcc acc[4] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
     Fp4 s_two = Fp4::zero();
-    for (uint32_t c = 0; c < a.n_all; c++) {
-        if (c == a.n_two)
+    // columns [from, to): eight loads in flight per step (a short-and-wide table — a precompile chip with a few hundred rows and
+    // thousands of columns — has too few rows to hide a pointer fetch + a load per column behind other waves)
+    auto sweep = [&](uint32_t from, uint32_t to) {
+        uint32_t c = from;
+        for (; c + 8 <= to; c += 8) {
+            uint32_t v[8];
 #pragma unroll
-            for (int k = 0; k < 4; k++) s_two.c[k] = acc[k].value();
-        const uint32_t v = a.cols[c][i];
-        const double vlo = (double)(v & 0xffffu), vhi = (double)(v >> 16);
+            for (int u = 0; u < 8; u++) v[u] = a.cols[c + u][i];
 #pragma unroll
-        for (int k = 0; k < 4; k++) acc[k].add(a.alpha_pows[4 * c + k], vlo, vhi);
-        if ((c & 31) == 31)
+            for (int u = 0; u < 8; u++) {
+                const double vlo = (double)(v[u] & 0xffffu), vhi = (double)(v[u] >> 16);
 #pragma unroll
-            for (int k = 0; k < 4; k++) acc[k].reduce();
-    }
+                for (int k = 0; k < 4; k++) acc[k].add(a.alpha_pows[4 * (c + u) + k], vlo, vhi);
+            }
+            // (at most 16 terms since the last reduction of this sweep: below the 32-term bound of DotAcc)
+            if (((c - from) & 8) != 0)
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc[k].reduce();
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[k].reduce();
+        for (; c < to; c++) {
+            const uint32_t v = a.cols[c][i];
+            const double vlo = (double)(v & 0xffffu), vhi = (double)(v >> 16);
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[k].add(a.alpha_pows[4 * c + k], vlo, vhi);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[k].reduce();
+    };
+    sweep(0, a.n_two);
+#pragma unroll
+    for (int k = 0; k < 4; k++) s_two.c[k] = acc[k].value();
+    sweep(a.n_two, a.n_all);
     Fp4 s;
 #pragma unroll
     for (int k = 0; k < 4; k++) s.c[k] = acc[k].value();

@@ -36,19 +36,30 @@ hipError_t launch_to_internal(hipStream_t st, uint32_t *d, size_t n);
 hipError_t launch_from_internal(hipStream_t st, uint32_t *d, size_t n);
 
 // merkle.hip
-// d_cols: device array of `ncols` column base pointers (each column has `height` words)
-hipError_t launch_merkle_leaves(hipStream_t st, const uint32_t *const *d_cols, uint32_t ncols, uint32_t log_height,
-                                uint32_t *d_out);
-// d_out[i] = compress(prev[i], prev[i + len]); with ncols > 0 additionally
-// d_out[i] = compress(d_out[i], sponge(row i of the injected columns))
-hipError_t launch_merkle_level(hipStream_t st, const uint32_t *d_prev, const uint32_t *const *d_cols, uint32_t ncols,
-                               uint32_t log_len, uint32_t *d_out);
-// every level below a layer of 2^log_start <= 2^MERKLE_TOP_LOG nodes, down to the root, in one launch
+// Row sponges of ONE tree in one launch: the leaves (the tallest matrices) and, for every lower level where shorter matrices
+// join the tree, the digests of their rows ("injected" at that level by launch_merkle_level / launch_merkle_top).  A short
+// and wide table (a precompile chip: 2^14 rows of 1245 columns = 156 sequential permutations per row on a few hundred
+// waves) is latency-bound on its own; in the same launch as the tall leaves its chain hides behind them.  Segments run in
+// the order given (the launch puts the longest chains first).
 constexpr uint32_t MERKLE_TOP_LOG = 6;   // below this the levels share one single-workgroup launch (16 lanes per node)
 constexpr uint32_t MERKLE_COOP_LOG = 13; // levels of at most 2^13 nodes run one node per 16 lanes (latency-, not throughput-bound)
-struct MerkleTopInject {  // per level lh (nodes = 2^lh): columns injected at that level
-    const uint32_t *const *cols[MERKLE_TOP_LOG + 1] = {};
-    uint32_t ncols[MERKLE_TOP_LOG + 1] = {};
+constexpr uint32_t MERKLE_MAX_SEGMENTS = 24;
+struct MerkleLeafSegments {
+    uint32_t n = 0;
+    const uint32_t *const *cols[MERKLE_MAX_SEGMENTS];   // device array of `ncols` column base pointers (2^log_h words each)
+    uint32_t *out[MERKLE_MAX_SEGMENTS];                 // [2^log_h][8] digests
+    uint32_t ncols[MERKLE_MAX_SEGMENTS], log_h[MERKLE_MAX_SEGMENTS];
+    uint32_t coop[MERKLE_MAX_SEGMENTS];                 // set by the launch: 16 lanes per row
+    uint32_t block0[MERKLE_MAX_SEGMENTS + 1];           // set by the launch: first workgroup of every segment
+    void add(const uint32_t *const *c, uint32_t nc, uint32_t lh, uint32_t *o) { cols[n] = c; ncols[n] = nc; log_h[n] = lh; out[n] = o; n++; }
+};
+hipError_t launch_merkle_leaves(hipStream_t st, MerkleLeafSegments sg);
+// d_out[i] = compress(prev[i], prev[i + len]); with d_inject additionally
+// d_out[i] = compress(d_out[i], d_inject[i])   (d_inject: the row digests of the matrices that join at this level)
+hipError_t launch_merkle_level(hipStream_t st, const uint32_t *d_prev, const uint32_t *d_inject, uint32_t log_len, uint32_t *d_out);
+// every level below a layer of 2^log_start <= 2^MERKLE_TOP_LOG nodes, down to the root, in one launch
+struct MerkleTopInject {  // per level lh (nodes = 2^lh): row digests injected at that level (or nullptr)
+    const uint32_t *digests[MERKLE_TOP_LOG + 1] = {};
 };
 hipError_t launch_merkle_top(hipStream_t st, uint32_t *d_layer, uint32_t log_start, const MerkleTopInject &inj);
 hipError_t launch_poseidon2_permute(hipStream_t st, uint32_t *d_states, size_t n);

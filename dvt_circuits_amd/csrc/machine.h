@@ -56,6 +56,13 @@ template <class Air>
 hipError_t launch_perm_t(hipStream_t st, const PermArgs &a) {
     if (Air::N_INTERACTIONS == 0) return hipSuccess;
     size_t n = (size_t)1 << a.log_n;
+    if constexpr (Air::N_LPARTS > 1 && Air::N_LPARTS <= PARTS_MAX) {
+        if (a.partial && a.log_n <= PARTS_PARALLEL_LOG) {
+            perm_rows_parts_kernel<Air><<<dim3((unsigned)((n + 255) / 256), Air::N_LPARTS), 256, 0, st>>>(a);
+            sum_parts_kernel<0><<<(unsigned)((4 * n + 255) / 256), 256, 0, st>>>(a.partial, Air::N_LPARTS, 4 * n, a.totals);
+            return hipGetLastError();
+        }
+    }
     perm_rows_kernel<Air><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(a);
     return hipGetLastError();
 }
@@ -69,6 +76,14 @@ void launch_quotient_parts(hipStream_t st, const QuotientArgs &a, unsigned block
 template <class Air>
 hipError_t launch_quotient_t(hipStream_t st, const QuotientArgs &a) {
     size_t m = (size_t)2 << a.log_n;
+    constexpr int NP = Air::N_PARTS + (Air::N_INTERACTIONS > 0 ? Air::N_LPARTS : 0);
+    if constexpr (NP > 2 && NP <= PARTS_MAX && Air::MAIN_W >= 128) {   // (the wide chips: the others' groups are few and short)
+        if (a.partial && a.log_n <= PARTS_PARALLEL_LOG) {
+            quotient_parts_kernel<Air><<<dim3((unsigned)((m + 255) / 256), NP), 256, 0, st>>>(a);
+            sum_parts_kernel<0><<<(unsigned)((4 * m + 255) / 256), 256, 0, st>>>(a.partial, NP, 4 * m, a.out);
+            return hipGetLastError();
+        }
+    }
     launch_quotient_parts<Air, 0>(st, a, (unsigned)((m + 255) / 256));
     return hipGetLastError();
 }

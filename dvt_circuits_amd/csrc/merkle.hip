@@ -16,6 +16,8 @@
 // HBM-bound.  The permutation runs on the FP64 pipe (poseidon2_f64.cuh: exact integers in doubles, 6 full-rate
 // operations per product instead of 3 quarter-rate integer multiplies); states stay in doubles between the
 // permutations of one sponge and are converted from / to the Montgomery words of HBM at the edges.
+#include <utility>
+
 #include "kernels.h"
 #include "poseidon2_f64.cuh"
 
@@ -58,65 +60,83 @@ __device__ __forceinline__ void load_children(const uint32_t *prev, size_t i, si
     for (int k = 0; k < 16; k++) s[k] = p2f::from_mont(w[k]);
 }
 
-__global__ void __launch_bounds__(256) merkle_leaves_kernel(const uint32_t *const *cols, uint32_t ncols, size_t height,
-                                                           uint32_t *out) {
-    size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= height) return;
-    double s[16];
-    hash_row(cols, ncols, row, s);
-    store_digest(out, row, s);
+// the same sponge with one row per 16 lanes (lane e holds state element e; rate = lanes 0..7)
+__device__ __forceinline__ double coop_hash_row(const uint32_t *const *cols, uint32_t ncols, size_t row, bool live, uint32_t e, const p2f::CoopConsts &k) {
+    double h = 0.0;
+    for (uint32_t g = 0; g < ncols; g += 8) {
+        if (e < 8 && g + e < ncols) h = p2f::from_mont(live ? cols[g + e][row] : 0u);
+        h = p2f::coop_permute(h, k);
+    }
+    return h;
+}
+
+// every row sponge of a tree: segment s owns workgroups [block0[s], block0[s + 1])
+__global__ void __launch_bounds__(256) merkle_leaves_kernel(MerkleLeafSegments sg) {
+    uint32_t s = 0;
+    while (s + 1 < sg.n && blockIdx.x >= sg.block0[s + 1]) s++;     // (wave-uniform)
+    const size_t t = (size_t)(blockIdx.x - sg.block0[s]) * blockDim.x + threadIdx.x;
+    const size_t height = (size_t)1 << sg.log_h[s];
+    if (sg.coop[s]) {
+        const uint32_t e = threadIdx.x & 15;
+        const p2f::CoopConsts k = p2f::coop_consts(e);
+        const size_t row = t >> 4;
+        const bool live = row < height;
+        const double h = coop_hash_row(sg.cols[s], sg.ncols[s], row, live, e, k);
+        if (live && e < 8) sg.out[s][row * 8 + e] = p2f::to_mont(h);
+        return;
+    }
+    if (t >= height) return;
+    double st[16];
+    hash_row(sg.cols[s], sg.ncols[s], t, st);
+    store_digest(sg.out[s], t, st);
 }
 
 // INJECT = false: the big levels of a tree (no shorter matrix joins there) - one permutation, one inlined copy of it.
 template <bool INJECT>
-__global__ void __launch_bounds__(256) merkle_level_kernel(const uint32_t *prev, const uint32_t *const *cols,
-                                                          uint32_t ncols, size_t len, uint32_t *out) {
+__global__ void __launch_bounds__(256) merkle_level_kernel(const uint32_t *prev, const uint32_t *inject, size_t len, uint32_t *out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= len) return;
     // natural-order pairing: children i and i + len (two coalesced 32-B-per-lane streams)
     double s[16];
     load_children(prev, i, len, s);
-    p2f::permute(s);
-    if constexpr (INJECT) {
-        double h[16];
-        hash_row(cols, ncols, i, h);
+    // (a loop, not two calls: ONE inlined copy of the permutation, see hash_row)
+#pragma unroll 1
+    for (int pass = 0; pass < (INJECT ? 2 : 1); pass++) {
+        if (pass) {
+            const uint4 *pd = reinterpret_cast<const uint4 *>(inject + i * 8);
+            const uint4 a = pd[0], b = pd[1];
+            const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-        for (int k = 0; k < 8; k++) s[8 + k] = h[k];
+            for (int k = 0; k < 8; k++) s[8 + k] = p2f::from_mont(w[k]);
+        }
         p2f::permute(s);
     }
     store_digest(out, i, s);
 }
 
 // ---- latency-bound levels: one node per 16 lanes (p2f::coop_permute) ---------------------------------------------------
-// node i of a level of `len` nodes = compress(child i, child i + len) [+ injected matrices]; lane e of the node's row holds
-// state element e.  Blocks are whole rows; rows beyond `len` run along (DPP needs the full row) and store nothing.
-__device__ __forceinline__ void coop_node(const uint32_t *prev, const uint32_t *const *cols, uint32_t ncols, size_t i, size_t len,
+// node i of a level of `len` nodes = compress(child i, child i + len) [then compress(node, injected row digest i)]; lane e of
+// the node's row holds state element e.  Blocks are whole rows; rows beyond `len` run along (DPP needs the full row) and
+// store nothing.
+__device__ __forceinline__ void coop_node(const uint32_t *prev, const uint32_t *inject, size_t i, size_t len,
                                           bool live, uint32_t e, const p2f::CoopConsts &k, uint32_t *out) {
     const size_t src = e < 8 ? i * 8 + e : (i + len) * 8 + (e - 8);
     double s = p2f::from_mont(live ? prev[src] : 0u);
     s = p2f::coop_permute(s, k);
-    if (ncols) {
-        // sponge over row i of the injected columns (rate 8 = lanes 0..7, capacity in lanes 8..15), then one more
-        // compression of (node, sponge digest)
-        double h = 0.0;
-        for (uint32_t g = 0; g < ncols; g += 8) {
-            if (e < 8 && g + e < ncols) h = p2f::from_mont(live ? cols[g + e][i] : 0u);
-            h = p2f::coop_permute(h, k);
-        }
-        // lanes 8..15 take the digest words 0..7 of the sponge (row rotation by 8), lanes 0..7 keep the node
-        const double hs = p2f::dpp_mov<p2f::DPP_ROW_ROR + 8>(h);
+    if (inject) {
+        // lanes 8..15 take the digest words 0..7 of the injected rows, lanes 0..7 keep the node
+        const double hs = p2f::from_mont(live && e >= 8 ? inject[i * 8 + (e - 8)] : 0u);
         s = e < 8 ? s : hs;
         s = p2f::coop_permute(s, k);
     }
     if (live && e < 8) out[i * 8 + e] = p2f::to_mont(s);
 }
 
-__global__ void __launch_bounds__(256) merkle_level_coop_kernel(const uint32_t *prev, const uint32_t *const *cols, uint32_t ncols,
-                                                               size_t len, uint32_t *out) {
+__global__ void __launch_bounds__(256) merkle_level_coop_kernel(const uint32_t *prev, const uint32_t *inject, size_t len, uint32_t *out) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t e = threadIdx.x & 15;
     const p2f::CoopConsts k = p2f::coop_consts(e);
-    coop_node(prev, cols, ncols, t >> 4, len, (t >> 4) < len, e, k, out);
+    coop_node(prev, inject, t >> 4, len, (t >> 4) < len, e, k, out);
 }
 
 // All levels from a layer of 2^log_start nodes (log_start <= MERKLE_TOP_LOG) down to the root in ONE
@@ -131,7 +151,7 @@ __global__ void __launch_bounds__(1024) merkle_top_kernel(uint32_t *layer, uint3
         const size_t len = (size_t)1 << lh;
         uint32_t *cur = prev + ((size_t)16 << lh);
         for (size_t base = 0; base < len; base += slots)       // uniform trip count: every row takes part in every pass
-            coop_node(prev, inj.cols[lh], inj.ncols[lh], base + slot, len, base + slot < len, e, k, cur);
+            coop_node(prev, inj.digests[lh], base + slot, len, base + slot < len, e, k, cur);
         __threadfence_block();
         __syncthreads();
         prev = cur;
@@ -160,25 +180,41 @@ __global__ void poseidon2_permute_kernel(uint32_t *states, size_t n) {
     for (int k = 0; k < 16; k++) states[i * 16 + k] = p2f::to_mont(s[k]);
 }
 
-hipError_t launch_merkle_leaves(hipStream_t st, const uint32_t *const *d_cols, uint32_t ncols, uint32_t log_height,
-                                uint32_t *d_out) {
-    size_t h = (size_t)1 << log_height;
-    unsigned blocks = (unsigned)((h + 255) / 256);
-    merkle_leaves_kernel<<<blocks, 256, 0, st>>>(d_cols, ncols, h, d_out);
+hipError_t launch_merkle_leaves(hipStream_t st, MerkleLeafSegments sg) {
+    if (!sg.n || sg.n > MERKLE_MAX_SEGMENTS) return hipErrorInvalidValue;
+    // longest sponge first (workgroups are dispatched in order), the many-row segments behind them.  A segment of few rows
+    // runs one row per 16 lanes when its chain at one row per thread (about 9 us per permutation on a wave that has a SIMD
+    // to itself) would outlast everything else in the launch (about 7 permutations per ns for the whole GPU).
+    for (uint32_t i = 1; i < sg.n; i++)
+        for (uint32_t j = i; j > 0 && sg.ncols[j] > sg.ncols[j - 1]; j--) {
+            std::swap(sg.cols[j], sg.cols[j - 1]); std::swap(sg.out[j], sg.out[j - 1]);
+            std::swap(sg.ncols[j], sg.ncols[j - 1]); std::swap(sg.log_h[j], sg.log_h[j - 1]);
+        }
+    double work_us = 0;
+    for (uint32_t i = 0; i < sg.n; i++) work_us += (double)((size_t)1 << sg.log_h[i]) * ((sg.ncols[i] + 7) / 8) / 7000.0;
+    uint32_t blocks = 0;
+    for (uint32_t i = 0; i < sg.n; i++) {
+        const double chain_us = 9.0 * ((sg.ncols[i] + 7) / 8);
+        sg.coop[i] = sg.log_h[i] <= MERKLE_COOP_LOG && chain_us > work_us;
+        sg.block0[i] = blocks;
+        const size_t threads = ((size_t)1 << sg.log_h[i]) * (sg.coop[i] ? 16 : 1);
+        blocks += (uint32_t)((threads + 255) / 256);
+    }
+    sg.block0[sg.n] = blocks;
+    merkle_leaves_kernel<<<blocks, 256, 0, st>>>(sg);
     return hipGetLastError();
 }
 
-hipError_t launch_merkle_level(hipStream_t st, const uint32_t *d_prev, const uint32_t *const *d_cols, uint32_t ncols,
-                               uint32_t log_len, uint32_t *d_out) {
+hipError_t launch_merkle_level(hipStream_t st, const uint32_t *d_prev, const uint32_t *d_inject, uint32_t log_len, uint32_t *d_out) {
     size_t len = (size_t)1 << log_len;
     if (log_len <= MERKLE_COOP_LOG) {  // too few nodes to fill the GPU with one thread each: 16 lanes per node
         unsigned blocks = (unsigned)((len * 16 + 255) / 256);
-        merkle_level_coop_kernel<<<blocks, 256, 0, st>>>(d_prev, d_cols, ncols, len, d_out);
+        merkle_level_coop_kernel<<<blocks, 256, 0, st>>>(d_prev, d_inject, len, d_out);
         return hipGetLastError();
     }
     unsigned blocks = (unsigned)((len + 255) / 256);
-    if (ncols) merkle_level_kernel<true><<<blocks, 256, 0, st>>>(d_prev, d_cols, ncols, len, d_out);
-    else merkle_level_kernel<false><<<blocks, 256, 0, st>>>(d_prev, d_cols, ncols, len, d_out);
+    if (d_inject) merkle_level_kernel<true><<<blocks, 256, 0, st>>>(d_prev, d_inject, len, d_out);
+    else merkle_level_kernel<false><<<blocks, 256, 0, st>>>(d_prev, d_inject, len, d_out);
     return hipGetLastError();
 }
 

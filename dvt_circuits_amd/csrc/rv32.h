@@ -500,12 +500,20 @@ struct ShardMeta {
     uint32_t index, start_pc, next_pc;
     size_t n_recs;
 };
+// the precompile calls of a shard grouped by the chip that proves them, in call order: what the GPU builds the rows of those
+// chips from (launch_k0_bigop_rows)
+struct BigOpBatches {
+    std::vector<BigOpEvent> ev[N_CHIPS];
+};
+// device_rows != nullptr (the product path): the field / curve precompile chips get their shape only (present, log_n) and
+// their calls are handed back in *device_rows; nullptr (CPU-only debug / test entry points): their rows are built here
 bool build_aux_host(const ShardMeta &meta, const std::vector<AluEvent> &alu, const std::vector<ShaExtEvent> &sha_ext,
                     const std::vector<ShaCmpEvent> &sha_cmp, const std::vector<BigOpEvent> &big, const std::vector<MemInitRow> *mem_rows, int exit_code,
-                    const HostPrep &prep, HostTraces *out, std::string *err);
-// the rows of the fp_op / fp2_op / bls_g1 / secp_k1 chips for the calls of one shard (rv32_bigops.hip); byte_mult[op][65536]
-// receives the byte-table lookups those rows make
-bool build_bigop_traces(const std::vector<BigOpEvent> &big, uint32_t shard, HostTraces *out, uint32_t *byte_mult, std::string *err);
+                    const HostPrep &prep, HostTraces *out, std::string *err, BigOpBatches *device_rows = nullptr);
+// the rows of the fp_op / fp2_op / bls_g1 / secp_k1 / u256_mul chips for the calls of one shard (rv32_bigops.hip);
+// byte_mult[op][65536] receives the byte-table lookups those rows make
+bool build_bigop_traces(const std::vector<BigOpEvent> &big, uint32_t shard, HostTraces *out, uint32_t *byte_mult, std::string *err,
+                        BigOpBatches *device_rows = nullptr);
 // the whole shard on the host, cpu chip included (debug C-ABI, tests)
 bool build_traces_host(const Program &prog, const ExecResult &res, size_t shard_pos, const HostPrep &prep, HostTraces *out, std::string *err);
 // instruction index -> row of the program table (provable instructions only; others map to row 0 and never occur)
@@ -514,6 +522,11 @@ std::vector<uint32_t> program_row_map(const Program &prog);
 #if defined(__HIPCC__)
 hipError_t launch_k0_cpu_rows(hipStream_t st, const CycleRec *d_recs, size_t n_recs, uint32_t shard, uint32_t shard_next_pc, const Instr *d_instrs,
                               const uint32_t *d_prog_row, uint32_t *d_cpu, uint32_t log_n, uint32_t *d_byte_mult, uint32_t *d_prog_mult);
+// K0 of a precompile chip: row i of the zeroed column-major trace d_main [W][2^log_n] (canonical words) from call d_ev[i], the
+// rows' byte-table lookups added to d_byte_mult (plain counts); *d_err receives the largest row error code (0 = none)
+hipError_t launch_k0_bigop_rows(hipStream_t st, int chip, const BigOpEvent *d_ev, uint32_t n_ev, uint32_t shard, uint32_t *d_main, uint32_t log_n,
+                                uint32_t *d_byte_mult, uint32_t *d_err);
+const char *bigop_row_error_text(uint32_t code);
 #endif
 
 }  // namespace rv32

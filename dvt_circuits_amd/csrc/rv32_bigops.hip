@@ -2,7 +2,8 @@
 // BLS12381_ADD / _DOUBLE, SECP256K1_ADD / _DOUBLE syscalls, which the reference's guests reach through the patched
 // bls12_381 / secp256k1 crates, reference crates/dkg/Cargo.toml:24-25): what a call computes (the guest machine's
 // semantics) and the rows of the four chips that prove the calls (tools/airgen/rv32.py: build_fp_op, build_fp2_op,
-// build_weierstrass).  Host code only.
+// build_weierstrass).  What a call computes is host code (the executor); the rows are built on the GPU (one thread per
+// call, k0_bigop_rows_kernel) and, for the CPU-only debug / test entry points, by the same code on the host.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -13,13 +14,14 @@
 #include "bigfield.h"
 #include "rv32.h"
 
-#if !defined(__HIP_DEVICE_COMPILE__)
-// (only the interactions of the five precompile chips are instantiated here, and those are loops: optimised as usual)
+// (only the interactions of the five precompile chips are instantiated here, and those are loops)
 #include "gen/air_rv32.inc"
 #include "gen/rv32_rels.h"
 
 namespace dvt {
 namespace rv32 {
+
+#if !defined(__HIP_DEVICE_COMPILE__)
 
 // ------------------------------------------------------------------ the fields
 static const uint64_t BLS_P[6] = {0xb9feffffffffaaabull, 0x1eabfffeb153ffffull, 0x6730d2a0f6b0f624ull, 0x64774b84f38512bfull, 0x4b1ba7b6434bacd7ull, 0x1a0111ea397fe69aull};
@@ -148,61 +150,79 @@ const char *bigop_compute(uint32_t code, const uint32_t *a, const uint32_t *b, u
     }
 }
 
-// ------------------------------------------------------------------ rows
+#endif  // host pass
+
+// ------------------------------------------------------------------ rows (host and device)
 namespace {
-// one row of a chip under construction: a contiguous scratch row (the chips are up to 1245 columns wide: writing the
-// cells straight into the column-major trace would be one cache miss per cell); scattered into the trace when complete
+// A row under construction.  Host: a contiguous scratch row (the chips are up to 1245 columns wide: writing the cells
+// straight into the column-major trace would be one cache miss per cell), scattered into the trace when complete.
+// Device: the cells of row `row` of the column-major trace itself (lane = row: coalesced).
 struct RowRef {
     uint32_t *m;
-    uint32_t get(int col) const { return m[col]; }
-    void put(int col, uint32_t v) { m[col] = v; }
-    void bytes(int col0, const uint32_t *w, int nwords) {
-        for (int k = 0; k < nwords; k++)
-            for (int i = 0; i < 4; i++) put(col0 + 4 * k + i, (w[k] >> (8 * i)) & 0xffu);
-    }
+    DVT_HD uint32_t get(int col) const { return m[col]; }
+    DVT_HD void put(int col, uint32_t v) { m[col] = v; }
 };
-// canonical residues with plain 64-bit arithmetic: what the walker below evaluates the interaction values in (cells are
-// canonical on the host; no Montgomery conversion per cell)
+struct DevRow {
+    uint32_t *m;
+    size_t n, row;
+    DVT_HD uint32_t get(int col) const { return m[(size_t)col * n + row]; }
+    DVT_HD void put(int col, uint32_t v) { m[(size_t)col * n + row] = v; }
+};
+template <class Row>
+DVT_HD void put_bytes(Row &R, int col0, const uint32_t *w, int nwords) {
+    for (int k = 0; k < nwords; k++)
+        for (int i = 0; i < 4; i++) R.put(col0 + 4 * k + i, (w[k] >> (8 * i)) & 0xffu);
+}
+// canonical residues with plain 64-bit arithmetic: what the walker below evaluates the interaction values in (the cells
+// are canonical while a row is built; no Montgomery conversion per cell)
 struct Cn {
     uint32_t v;
 };
-static inline Cn operator+(Cn a, Cn b) { uint32_t s = a.v + b.v; return Cn{s >= P ? s - P : s}; }
-static inline Cn operator-(Cn a, Cn b) { return Cn{a.v >= b.v ? a.v - b.v : a.v + P - b.v}; }
-static inline Cn operator-(Cn a) { return Cn{a.v ? P - a.v : 0}; }
-static inline Cn operator*(Cn a, Cn b) { return Cn{(uint32_t)((uint64_t)a.v * b.v % P)}; }
-// walks the generated interactions of a chip on one (host) row and counts its byte-table lookups
+DVT_HD Cn operator+(Cn a, Cn b) { uint32_t s = a.v + b.v; return Cn{s >= P ? s - P : s}; }
+DVT_HD Cn operator-(Cn a, Cn b) { return Cn{a.v >= b.v ? a.v - b.v : a.v + P - b.v}; }
+DVT_HD Cn operator-(Cn a) { return Cn{a.v ? P - a.v : 0}; }
+DVT_HD Cn operator*(Cn a, Cn b) { return Cn{(uint32_t)((uint64_t)a.v * b.v % P)}; }
+// walks the generated interactions of a chip on one row and counts its byte-table lookups (plain integer counts; on the
+// device the table is the shard's, shared with K0 of the cpu rows: atomics)
+template <class Row>
 struct LookupCtx {
     using T = Cn;
-    const RowRef &r;
+    const Row &r;
     const uint32_t *pubs;
     uint32_t *byte_mult;
-    static T K(uint32_t monty) { return Cn{Fp::raw(monty).canonical()}; }
-    static T KI(uint32_t canonical) { return Cn{canonical}; }
-    T main(int c, int rot) const { (void)rot; return Cn{r.get(c)}; }   // (the precompile chips' interactions read the local row only)
-    T prep(int, int) const { return Cn{0}; }
-    T pub(int k) const { return Cn{pubs[k]}; }
-    void interaction(int, int bus, int sign, int, const T &mult, const T *vals, int) {
+    DVT_HD static T K(uint32_t monty) { return Cn{Fp::raw(monty).canonical()}; }
+    DVT_HD static T KI(uint32_t canonical) { return Cn{canonical}; }
+    DVT_HD T main(int c, int rot) const { (void)rot; return Cn{r.get(c)}; }   // (the precompile chips' interactions read the local row only)
+    DVT_HD T prep(int, int) const { return Cn{0}; }
+    DVT_HD T pub(int k) const { return Cn{pubs[k]}; }
+    DVT_HD void interaction(int, int bus, int sign, int, const T &mult, const T *vals, int) {
         if (bus != 2 || sign < 0) return;   // bus 2 = byte (tools/airgen/rv32.py BUSES)
         if (!mult.v) return;
         const uint32_t op = vals[0].v, b = vals[2].v, c = vals[3].v;
-        byte_mult[(size_t)(op - 1) * 65536 + (op == B_U16 ? b : (b << 8) | c)] += mult.v;
+        uint32_t *slot = byte_mult + (size_t)(op - 1) * 65536 + (op == B_U16 ? b : (b << 8) | c);
+#if defined(__HIP_DEVICE_COMPILE__)
+        atomicAdd(slot, mult.v);
+#else
+        *slot += mult.v;
+#endif
     }
 };
 
-static uint32_t ceil_log2(size_t n) { uint32_t l = 0; while (((size_t)1 << l) < n) l++; return l; }
-
 // the (shard, clk) a word carried before the access at (shard, ts): same-shard flag and the two limbs of the gap
-static void mem_meta(RowRef &R, int col_sh0, int k, uint32_t psh, uint32_t pts, uint32_t shard, uint32_t ts) {
+template <class Row>
+DVT_HD void mem_meta(Row &R, int col_sh0, int k, uint32_t psh, uint32_t pts, uint32_t shard, uint32_t ts) {
     const uint32_t d = psh == shard ? ts - pts - 1 : shard - psh - 1;
     const int c = col_sh0 + 5 * k;   // sh, ts, same, lo, hi of word k are consecutive columns
     R.put(c, psh); R.put(c + 1, pts); R.put(c + 2, psh == shard); R.put(c + 3, d & 0xffff); R.put(c + 4, d >> 16);
 }
 // v < modulus witnessed on 3-byte groups: one-hot flag of the most significant differing group, modulus_g - v_g - 1 there
-static bool fill_lt(RowRef &R, int col_f0, int col_d0, int col_v0, int L, const uint8_t *mod) {
+// (Mod: uint8_t mod(int i))
+template <class Row, class Mod>
+DVT_HD bool fill_lt(Row &R, int col_f0, int col_d0, int col_v0, int L, const Mod &mod) {
     const int G = (L + 2) / 3;
     for (int g = G - 1; g >= 0; g--) {
         uint32_t vg = 0, mg = 0;
-        for (int t = 0; t < 3 && 3 * g + t < L; t++) { vg |= R.get(col_v0 + 3 * g + t) << (8 * t); mg |= (uint32_t)mod[3 * g + t] << (8 * t); }
+        for (int t = 0; t < 3 && 3 * g + t < L; t++) { vg |= R.get(col_v0 + 3 * g + t) << (8 * t); mg |= (uint32_t)mod(3 * g + t) << (8 * t); }
         if (vg == mg) continue;
         if (vg > mg) return false;
         const uint32_t d = mg - vg - 1;
@@ -212,7 +232,18 @@ static bool fill_lt(RowRef &R, int col_f0, int col_d0, int col_v0, int L, const 
     }
     return false;   // equal to the modulus
 }
-static bool fill_differ(RowRef &R, int col_z0, int col_a0, int col_b0, int L) {
+struct ConstMod {
+    const uint8_t *m;
+    DVT_HD uint8_t operator()(int i) const { return m[i]; }
+};
+template <class Row>
+struct RowMod {   // a modulus held in the row itself (UINT256_MUL)
+    const Row &R;
+    int col0;
+    DVT_HD uint8_t operator()(int i) const { return (uint8_t)R.get(col0 + i); }
+};
+template <class Row>
+DVT_HD bool fill_differ(Row &R, int col_z0, int col_a0, int col_b0, int L) {
     const int G = (L + 2) / 3;
     for (int g = 0; g < G; g++) {
         uint32_t ag = 0, bg = 0;
@@ -224,13 +255,21 @@ static bool fill_differ(RowRef &R, int col_z0, int col_a0, int col_b0, int L) {
     return false;
 }
 
-template <class Air>
-static bool finish_row(RowRef &R, const PolyRelDesc *rels, int nrels, const uint32_t *pubs, uint32_t *byte_mult, std::string *err) {
+// reasons a row cannot be built (the executor traps on every one of them first: seeing one here is an internal error)
+enum RowError { ROW_OK = 0, ROW_NO_WITNESS, ROW_FP_NOT_REDUCED, ROW_FP2_NOT_REDUCED, ROW_U256_NOT_BELOW, ROW_CURVE_BAD, ROW_N_ERRORS };
+#if !defined(__HIP_DEVICE_COMPILE__)
+const char *const ROW_ERROR_TEXT[ROW_N_ERRORS] = {
+    "", "precompile row: an identity has no witness", "fp_op: result not reduced", "fp2_op: result not reduced", "u256_mul: result not below the modulus",
+    "curve precompile row: a coordinate is not reduced or the abscissae are equal"};
+#endif
+
+template <class Air, class Row>
+DVT_HD RowError finish_row(Row &R, const PolyRelDesc *rels, int nrels, const uint32_t *pubs, uint32_t *byte_mult) {
     for (int i = 0; i < nrels; i++)
-        if (!solve_poly_rel(rels[i], R)) { if (err) *err = std::string("precompile row: identity '") + rels[i].name + "' has no witness"; return false; }
-    LookupCtx ctx{R, pubs, byte_mult};
+        if (!solve_poly_rel(rels[i], R)) return ROW_NO_WITNESS;
+    LookupCtx<Row> ctx{R, pubs, byte_mult};
     Air::interactions(ctx);
-    return true;
+    return ROW_OK;
 }
 
 struct WCols {   // column ids of a short-Weierstrass chip
@@ -240,9 +279,118 @@ struct WCols {   // column ids of a short-Weierstrass chip
 #define DVT_WCOLS(P) WCols{P##is_real, P##is_add, P##is_dbl, P##clk, P##pp_0, P##qp_0, P##x1_0, P##y1_0, P##x2_0, P##y2_0, P##lam_0, P##x3_0, P##y3_0, \
                            P##mq_sh_0, P##mp_sh_0, P##x1lt_f_0, P##x1lt_d_0, P##y1lt_f_0, P##y1lt_d_0, P##x2lt_f_0, P##x2lt_d_0, P##y2lt_f_0, P##y2lt_d_0, \
                            P##x3lt_f_0, P##x3lt_d_0, P##y3lt_f_0, P##y3lt_d_0, P##xne_z_0}
+
+// every cell of the row of call `e` in chip CHIP (the row starts all-zero), its byte-table lookups counted
+template <int CHIP, class Row>
+DVT_HD RowError fill_bigop_row(const BigOpEvent &e, uint32_t shard, Row &R, uint32_t *byte_mult) {
+    const uint32_t pubs[N_PUBLIC] = {0, 0, 0, shard, 0};   // (the chips read PUB_SHARD only)
+    const uint32_t ptrs[2] = {e.a_ptr, e.b_ptr};
+    if constexpr (CHIP == RV32_CHIP_FP_OP) {
+        const int op = (int)(e.code - SYS_BLS12381_FP_ADD);
+        R.put(RV32_FP_OP_is_real, 1); R.put(op == 0 ? RV32_FP_OP_is_add : op == 1 ? RV32_FP_OP_is_sub : RV32_FP_OP_is_mul, 1);
+        R.put(RV32_FP_OP_clk, e.clk);
+        put_bytes(R, RV32_FP_OP_xp_0, &ptrs[0], 1); put_bytes(R, RV32_FP_OP_yp_0, &ptrs[1], 1);
+        put_bytes(R, RV32_FP_OP_x_0, e.a, 12); put_bytes(R, RV32_FP_OP_y_0, e.b, 12); put_bytes(R, RV32_FP_OP_r_0, e.r, 12);
+        for (int k = 0; k < 12; k++) {
+            mem_meta(R, RV32_FP_OP_my_sh_0, k, e.b_sh[k], e.b_ts[k], shard, e.clk + 2);
+            mem_meta(R, RV32_FP_OP_mx_sh_0, k, e.a_sh[k], e.a_ts[k], shard, e.clk + 3);
+        }
+        if (!fill_lt(R, RV32_FP_OP_rlt_f_0, RV32_FP_OP_rlt_d_0, RV32_FP_OP_r_0, 48, ConstMod{rels_rv32::fp_op_0_mod})) return ROW_FP_NOT_REDUCED;
+        return finish_row<air_rv32::FpOp>(R, rels_rv32::fp_op, rels_rv32::fp_op_n, pubs, byte_mult);
+    } else if constexpr (CHIP == RV32_CHIP_U256_MUL) {
+        R.put(RV32_U256_MUL_is_real, 1); R.put(RV32_U256_MUL_clk, e.clk);
+        put_bytes(R, RV32_U256_MUL_xp_0, &ptrs[0], 1); put_bytes(R, RV32_U256_MUL_yp_0, &ptrs[1], 1);
+        put_bytes(R, RV32_U256_MUL_x_0, e.a, 8); put_bytes(R, RV32_U256_MUL_y_0, e.b, 8); put_bytes(R, RV32_U256_MUL_m_0, e.b + 8, 8); put_bytes(R, RV32_U256_MUL_r_0, e.r, 8);
+        for (int k = 0; k < 16; k++) mem_meta(R, RV32_U256_MUL_my_sh_0, k, e.b_sh[k], e.b_ts[k], shard, e.clk + 2);
+        for (int k = 0; k < 8; k++) mem_meta(R, RV32_U256_MUL_mx_sh_0, k, e.a_sh[k], e.a_ts[k], shard, e.clk + 3);
+        bool mzero = true;
+        for (int i = 0; i < 8; i++) mzero = mzero && e.b[8 + i] == 0;
+        R.put(RV32_U256_MUL_m_zero, mzero);
+        if (!mzero) {
+            // an inverse of one non-zero 3-byte group of m, and r < m
+            for (int g = 0; g < 11; g++) {
+                uint32_t mg = 0;
+                for (int t = 0; t < 3 && 3 * g + t < 32; t++) mg |= R.get(RV32_U256_MUL_m_0 + 3 * g + t) << (8 * t);
+                if (mg) { R.put(RV32_U256_MUL_mz_0 + g, inv(Fp::from_canonical(mg)).canonical()); break; }
+            }
+            if (!fill_lt(R, RV32_U256_MUL_rlt_f_0, RV32_U256_MUL_rlt_d_0, RV32_U256_MUL_r_0, 32, RowMod<Row>{R, RV32_U256_MUL_m_0})) return ROW_U256_NOT_BELOW;
+        }
+        return finish_row<air_rv32::U256Mul>(R, rels_rv32::u256_mul, rels_rv32::u256_mul_n, pubs, byte_mult);
+    } else if constexpr (CHIP == RV32_CHIP_FP2_OP) {
+        const int op = (int)(e.code - SYS_BLS12381_FP2_ADD);
+        R.put(RV32_FP2_OP_is_real, 1); R.put(op == 0 ? RV32_FP2_OP_is_add : op == 1 ? RV32_FP2_OP_is_sub : RV32_FP2_OP_is_mul, 1);
+        R.put(RV32_FP2_OP_clk, e.clk);
+        put_bytes(R, RV32_FP2_OP_xp_0, &ptrs[0], 1); put_bytes(R, RV32_FP2_OP_yp_0, &ptrs[1], 1);
+        put_bytes(R, RV32_FP2_OP_x0_0, e.a, 12); put_bytes(R, RV32_FP2_OP_x1_0, e.a + 12, 12);
+        put_bytes(R, RV32_FP2_OP_y0_0, e.b, 12); put_bytes(R, RV32_FP2_OP_y1_0, e.b + 12, 12);
+        put_bytes(R, RV32_FP2_OP_r0_0, e.r, 12); put_bytes(R, RV32_FP2_OP_r1_0, e.r + 12, 12);
+        for (int k = 0; k < 24; k++) {
+            mem_meta(R, RV32_FP2_OP_my_sh_0, k, e.b_sh[k], e.b_ts[k], shard, e.clk + 2);
+            mem_meta(R, RV32_FP2_OP_mx_sh_0, k, e.a_sh[k], e.a_ts[k], shard, e.clk + 3);
+        }
+        if (!fill_lt(R, RV32_FP2_OP_r0lt_f_0, RV32_FP2_OP_r0lt_d_0, RV32_FP2_OP_r0_0, 48, ConstMod{rels_rv32::fp2_op_0_mod}) ||
+            !fill_lt(R, RV32_FP2_OP_r1lt_f_0, RV32_FP2_OP_r1lt_d_0, RV32_FP2_OP_r1_0, 48, ConstMod{rels_rv32::fp2_op_0_mod})) return ROW_FP2_NOT_REDUCED;
+        return finish_row<air_rv32::Fp2Op>(R, rels_rv32::fp2_op, rels_rv32::fp2_op_n, pubs, byte_mult);
+    } else {
+        constexpr bool is_bls = CHIP == RV32_CHIP_BLS_G1;
+        const WCols C = is_bls ? DVT_WCOLS(RV32_BLS_G1_) : DVT_WCOLS(RV32_SECP_K1_);
+        constexpr int L = is_bls ? 48 : 32, W = L / 4;     // bytes / words per coordinate
+        const ConstMod mod{is_bls ? rels_rv32::bls_g1_0_mod : rels_rv32::secp_k1_0_mod};
+        const bool add = e.code == SYS_BLS12381_ADD || e.code == SYS_SECP256K1_ADD;
+        R.put(C.is_real, 1); R.put(add ? C.is_add : C.is_dbl, 1); R.put(C.clk, e.clk);
+        put_bytes(R, C.pp, &ptrs[0], 1); put_bytes(R, C.qp, &ptrs[1], 1);
+        put_bytes(R, C.x1, e.a, W); put_bytes(R, C.y1, e.a + W, W);
+        if (add) { put_bytes(R, C.x2, e.b, W); put_bytes(R, C.y2, e.b + W, W); }
+        put_bytes(R, C.lam, e.lam, W); put_bytes(R, C.x3, e.r, W); put_bytes(R, C.y3, e.r + W, W);
+        for (int k = 0; k < 2 * W; k++) {
+            if (add) mem_meta(R, C.mq_sh, k, e.b_sh[k], e.b_ts[k], shard, e.clk + 2);
+            mem_meta(R, C.mp_sh, k, e.a_sh[k], e.a_ts[k], shard, e.clk + 3);
+        }
+        bool ok = fill_lt(R, C.x1lt_f, C.x1lt_d, C.x1, L, mod) && fill_lt(R, C.y1lt_f, C.y1lt_d, C.y1, L, mod) &&
+                  fill_lt(R, C.x3lt_f, C.x3lt_d, C.x3, L, mod) && fill_lt(R, C.y3lt_f, C.y3lt_d, C.y3, L, mod);
+        if (add) ok = ok && fill_lt(R, C.x2lt_f, C.x2lt_d, C.x2, L, mod) && fill_lt(R, C.y2lt_f, C.y2lt_d, C.y2, L, mod) && fill_differ(R, C.xne_z, C.x1, C.x2, L);
+        if (!ok) return ROW_CURVE_BAD;
+        if constexpr (is_bls) return finish_row<air_rv32::BlsG1>(R, rels_rv32::bls_g1, rels_rv32::bls_g1_n, pubs, byte_mult);
+        else return finish_row<air_rv32::SecpK1>(R, rels_rv32::secp_k1, rels_rv32::secp_k1_n, pubs, byte_mult);
+    }
+}
 }  // namespace
 
-bool build_bigop_traces(const std::vector<BigOpEvent> &big, uint32_t shard, HostTraces *out, uint32_t *byte_mult, std::string *err) {
+// ------------------------------------------------------------------ device: one thread per call
+#if defined(__HIPCC__)
+template <int CHIP>
+__global__ void __launch_bounds__(64) k0_bigop_rows_kernel(const BigOpEvent *ev, uint32_t n_ev, uint32_t shard, uint32_t *main, uint32_t log_n, uint32_t *byte_mult,
+                                                           uint32_t *err) {
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_ev) return;
+    DevRow R{main, (size_t)1 << log_n, row};
+    const RowError e = fill_bigop_row<CHIP>(ev[row], shard, R, byte_mult);
+    if (e != ROW_OK) atomicMax(err, (uint32_t)e);
+}
+
+hipError_t launch_k0_bigop_rows(hipStream_t st, int chip, const BigOpEvent *d_ev, uint32_t n_ev, uint32_t shard, uint32_t *d_main, uint32_t log_n,
+                                uint32_t *d_byte_mult, uint32_t *d_err) {
+    if (!n_ev) return hipSuccess;
+    if (((size_t)1 << log_n) < n_ev) return hipErrorInvalidValue;
+    const unsigned blocks = (n_ev + 63) / 64;
+    switch (chip) {
+    case RV32_CHIP_FP_OP: k0_bigop_rows_kernel<RV32_CHIP_FP_OP><<<blocks, 64, 0, st>>>(d_ev, n_ev, shard, d_main, log_n, d_byte_mult, d_err); break;
+    case RV32_CHIP_FP2_OP: k0_bigop_rows_kernel<RV32_CHIP_FP2_OP><<<blocks, 64, 0, st>>>(d_ev, n_ev, shard, d_main, log_n, d_byte_mult, d_err); break;
+    case RV32_CHIP_BLS_G1: k0_bigop_rows_kernel<RV32_CHIP_BLS_G1><<<blocks, 64, 0, st>>>(d_ev, n_ev, shard, d_main, log_n, d_byte_mult, d_err); break;
+    case RV32_CHIP_SECP_K1: k0_bigop_rows_kernel<RV32_CHIP_SECP_K1><<<blocks, 64, 0, st>>>(d_ev, n_ev, shard, d_main, log_n, d_byte_mult, d_err); break;
+    case RV32_CHIP_U256_MUL: k0_bigop_rows_kernel<RV32_CHIP_U256_MUL><<<blocks, 64, 0, st>>>(d_ev, n_ev, shard, d_main, log_n, d_byte_mult, d_err); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+#endif
+
+// ------------------------------------------------------------------ host: shapes, and the rows for the CPU-only entry points
+#if !defined(__HIP_DEVICE_COMPILE__)
+static uint32_t ceil_log2(size_t n) { uint32_t l = 0; while (((size_t)1 << l) < n) l++; return l; }
+const char *bigop_row_error_text(uint32_t code) { return code < ROW_N_ERRORS ? ROW_ERROR_TEXT[code] : "precompile row: unknown error"; }
+
+bool build_bigop_traces(const std::vector<BigOpEvent> &big, uint32_t shard, HostTraces *out, uint32_t *byte_mult, std::string *err, BigOpBatches *device_rows) {
     HostTraces &T = *out;
     const auto t_begin = std::chrono::steady_clock::now();
     struct Report {
@@ -255,104 +403,45 @@ bool build_bigop_traces(const std::vector<BigOpEvent> &big, uint32_t shard, Host
         if (!bigop_info(e.code, &bi)) { if (err) *err = "precompile event with an unknown code"; return false; }
         by_chip[bi.chip].push_back(&e);
     }
-    const uint32_t pubs[N_PUBLIC] = {0, 0, 0, shard, 0};   // (the chips read PUB_SHARD only)
     static const int widths[N_CHIPS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, RV32_FP_OP_MAIN_W, RV32_FP2_OP_MAIN_W, RV32_BLS_G1_MAIN_W, RV32_SECP_K1_MAIN_W, RV32_U256_MUL_MAIN_W};
     for (int chip : {RV32_CHIP_FP_OP, RV32_CHIP_FP2_OP, RV32_CHIP_BLS_G1, RV32_CHIP_SECP_K1, RV32_CHIP_U256_MUL}) {
         auto &evs = by_chip[chip];
         T.present[chip] = !evs.empty();
         T.log_n[chip] = 0;
         T.main[chip].clear();
+        if (device_rows) device_rows->ev[chip].clear();
         if (evs.empty()) continue;
         const uint32_t lg = ceil_log2(evs.size());
         const size_t n = (size_t)1 << lg;
         T.log_n[chip] = lg;
+        if (device_rows) {   // the product path: the GPU builds the rows (launch_k0_bigop_rows) from the calls themselves
+            device_rows->ev[chip].reserve(evs.size());
+            for (auto *e : evs) device_rows->ev[chip].push_back(*e);
+            continue;
+        }
         T.main[chip].assign((size_t)widths[chip] * n, 0);
         std::vector<uint32_t> scratch(widths[chip]);
         for (size_t row = 0; row < evs.size(); row++) {
             const BigOpEvent &e = *evs[row];
             std::fill(scratch.begin(), scratch.end(), 0u);
             RowRef R{scratch.data()};
-            struct Scatter {   // the finished row goes to its place in the column-major trace when the iteration ends
-                uint32_t *dst; const uint32_t *src; size_t n, row; int w;
-                ~Scatter() { for (int c = 0; c < w; c++) if (src[c]) dst[(size_t)c * n + row] = src[c]; }
-            } scatter{T.main[chip].data(), scratch.data(), n, row, widths[chip]};
-            BigOpInfo bi;
-            bigop_info(e.code, &bi);
-            uint32_t ptrs[2] = {e.a_ptr, e.b_ptr};
-            if (chip == RV32_CHIP_FP_OP) {
-                const int op = (int)(e.code - SYS_BLS12381_FP_ADD);
-                R.put(RV32_FP_OP_is_real, 1); R.put(op == 0 ? RV32_FP_OP_is_add : op == 1 ? RV32_FP_OP_is_sub : RV32_FP_OP_is_mul, 1);
-                R.put(RV32_FP_OP_clk, e.clk);
-                R.bytes(RV32_FP_OP_xp_0, &ptrs[0], 1); R.bytes(RV32_FP_OP_yp_0, &ptrs[1], 1);
-                R.bytes(RV32_FP_OP_x_0, e.a, 12); R.bytes(RV32_FP_OP_y_0, e.b, 12); R.bytes(RV32_FP_OP_r_0, e.r, 12);
-                for (int k = 0; k < 12; k++) {
-                    mem_meta(R, RV32_FP_OP_my_sh_0, k, e.b_sh[k], e.b_ts[k], shard, e.clk + 2);
-                    mem_meta(R, RV32_FP_OP_mx_sh_0, k, e.a_sh[k], e.a_ts[k], shard, e.clk + 3);
-                }
-                if (!fill_lt(R, RV32_FP_OP_rlt_f_0, RV32_FP_OP_rlt_d_0, RV32_FP_OP_r_0, 48, rels_rv32::fp_op_0_mod)) { if (err) *err = "fp_op: result not reduced"; return false; }
-                if (!finish_row<air_rv32::FpOp>(R, rels_rv32::fp_op, rels_rv32::fp_op_n, pubs, byte_mult, err)) return false;
-            } else if (chip == RV32_CHIP_U256_MUL) {
-                R.put(RV32_U256_MUL_is_real, 1); R.put(RV32_U256_MUL_clk, e.clk);
-                R.bytes(RV32_U256_MUL_xp_0, &ptrs[0], 1); R.bytes(RV32_U256_MUL_yp_0, &ptrs[1], 1);
-                R.bytes(RV32_U256_MUL_x_0, e.a, 8); R.bytes(RV32_U256_MUL_y_0, e.b, 8); R.bytes(RV32_U256_MUL_m_0, e.b + 8, 8); R.bytes(RV32_U256_MUL_r_0, e.r, 8);
-                for (int k = 0; k < 16; k++) mem_meta(R, RV32_U256_MUL_my_sh_0, k, e.b_sh[k], e.b_ts[k], shard, e.clk + 2);
-                for (int k = 0; k < 8; k++) mem_meta(R, RV32_U256_MUL_mx_sh_0, k, e.a_sh[k], e.a_ts[k], shard, e.clk + 3);
-                uint8_t mb[32];
-                bool mzero = true;
-                for (int i = 0; i < 32; i++) { mb[i] = (uint8_t)(e.b[8 + i / 4] >> (8 * (i % 4))); mzero = mzero && mb[i] == 0; }
-                R.put(RV32_U256_MUL_m_zero, mzero);
-                if (!mzero) {
-                    // an inverse of one non-zero 3-byte group of m, and r < m
-                    for (int g = 0; g < 11; g++) {
-                        uint32_t mg = 0;
-                        for (int t = 0; t < 3 && 3 * g + t < 32; t++) mg |= (uint32_t)mb[3 * g + t] << (8 * t);
-                        if (mg) { R.put(RV32_U256_MUL_mz_0 + g, inv(Fp::from_canonical(mg)).canonical()); break; }
-                    }
-                    if (!fill_lt(R, RV32_U256_MUL_rlt_f_0, RV32_U256_MUL_rlt_d_0, RV32_U256_MUL_r_0, 32, mb)) { if (err) *err = "u256_mul: result not below the modulus"; return false; }
-                }
-                if (!finish_row<air_rv32::U256Mul>(R, rels_rv32::u256_mul, rels_rv32::u256_mul_n, pubs, byte_mult, err)) return false;
-            } else if (chip == RV32_CHIP_FP2_OP) {
-                const int op = (int)(e.code - SYS_BLS12381_FP2_ADD);
-                R.put(RV32_FP2_OP_is_real, 1); R.put(op == 0 ? RV32_FP2_OP_is_add : op == 1 ? RV32_FP2_OP_is_sub : RV32_FP2_OP_is_mul, 1);
-                R.put(RV32_FP2_OP_clk, e.clk);
-                R.bytes(RV32_FP2_OP_xp_0, &ptrs[0], 1); R.bytes(RV32_FP2_OP_yp_0, &ptrs[1], 1);
-                R.bytes(RV32_FP2_OP_x0_0, e.a, 12); R.bytes(RV32_FP2_OP_x1_0, e.a + 12, 12);
-                R.bytes(RV32_FP2_OP_y0_0, e.b, 12); R.bytes(RV32_FP2_OP_y1_0, e.b + 12, 12);
-                R.bytes(RV32_FP2_OP_r0_0, e.r, 12); R.bytes(RV32_FP2_OP_r1_0, e.r + 12, 12);
-                for (int k = 0; k < 24; k++) {
-                    mem_meta(R, RV32_FP2_OP_my_sh_0, k, e.b_sh[k], e.b_ts[k], shard, e.clk + 2);
-                    mem_meta(R, RV32_FP2_OP_mx_sh_0, k, e.a_sh[k], e.a_ts[k], shard, e.clk + 3);
-                }
-                if (!fill_lt(R, RV32_FP2_OP_r0lt_f_0, RV32_FP2_OP_r0lt_d_0, RV32_FP2_OP_r0_0, 48, rels_rv32::fp2_op_0_mod) ||
-                    !fill_lt(R, RV32_FP2_OP_r1lt_f_0, RV32_FP2_OP_r1lt_d_0, RV32_FP2_OP_r1_0, 48, rels_rv32::fp2_op_0_mod)) { if (err) *err = "fp2_op: result not reduced"; return false; }
-                if (!finish_row<air_rv32::Fp2Op>(R, rels_rv32::fp2_op, rels_rv32::fp2_op_n, pubs, byte_mult, err)) return false;
-            } else {
-                const bool is_bls = chip == RV32_CHIP_BLS_G1;
-                const WCols C = is_bls ? DVT_WCOLS(RV32_BLS_G1_) : DVT_WCOLS(RV32_SECP_K1_);
-                const int L = is_bls ? 48 : 32, W = L / 4;     // bytes / words per coordinate
-                const uint8_t *mod = is_bls ? rels_rv32::bls_g1_0_mod : rels_rv32::secp_k1_0_mod;
-                const bool add = bi.words_b != 0;
-                R.put(C.is_real, 1); R.put(add ? C.is_add : C.is_dbl, 1); R.put(C.clk, e.clk);
-                R.bytes(C.pp, &ptrs[0], 1); R.bytes(C.qp, &ptrs[1], 1);
-                R.bytes(C.x1, e.a, W); R.bytes(C.y1, e.a + W, W);
-                if (add) { R.bytes(C.x2, e.b, W); R.bytes(C.y2, e.b + W, W); }
-                R.bytes(C.lam, e.lam, W); R.bytes(C.x3, e.r, W); R.bytes(C.y3, e.r + W, W);
-                for (int k = 0; k < 2 * W; k++) {
-                    if (add) mem_meta(R, C.mq_sh, k, e.b_sh[k], e.b_ts[k], shard, e.clk + 2);
-                    mem_meta(R, C.mp_sh, k, e.a_sh[k], e.a_ts[k], shard, e.clk + 3);
-                }
-                bool ok = fill_lt(R, C.x1lt_f, C.x1lt_d, C.x1, L, mod) && fill_lt(R, C.y1lt_f, C.y1lt_d, C.y1, L, mod) &&
-                          fill_lt(R, C.x3lt_f, C.x3lt_d, C.x3, L, mod) && fill_lt(R, C.y3lt_f, C.y3lt_d, C.y3, L, mod);
-                if (add) ok = ok && fill_lt(R, C.x2lt_f, C.x2lt_d, C.x2, L, mod) && fill_lt(R, C.y2lt_f, C.y2lt_d, C.y2, L, mod) && fill_differ(R, C.xne_z, C.x1, C.x2, L);
-                if (!ok) { if (err) *err = "curve precompile row: a coordinate is not reduced or the abscissae are equal"; return false; }
-                if (is_bls ? !finish_row<air_rv32::BlsG1>(R, rels_rv32::bls_g1, rels_rv32::bls_g1_n, pubs, byte_mult, err)
-                           : !finish_row<air_rv32::SecpK1>(R, rels_rv32::secp_k1, rels_rv32::secp_k1_n, pubs, byte_mult, err)) return false;
+            RowError re = ROW_OK;
+            switch (chip) {
+            case RV32_CHIP_FP_OP: re = fill_bigop_row<RV32_CHIP_FP_OP>(e, shard, R, byte_mult); break;
+            case RV32_CHIP_FP2_OP: re = fill_bigop_row<RV32_CHIP_FP2_OP>(e, shard, R, byte_mult); break;
+            case RV32_CHIP_BLS_G1: re = fill_bigop_row<RV32_CHIP_BLS_G1>(e, shard, R, byte_mult); break;
+            case RV32_CHIP_SECP_K1: re = fill_bigop_row<RV32_CHIP_SECP_K1>(e, shard, R, byte_mult); break;
+            default: re = fill_bigop_row<RV32_CHIP_U256_MUL>(e, shard, R, byte_mult); break;
             }
+            if (re != ROW_OK) { if (err) *err = ROW_ERROR_TEXT[re]; return false; }
+            uint32_t *dst = T.main[chip].data();
+            for (int c = 0; c < widths[chip]; c++)
+                if (scratch[c]) dst[(size_t)c * n + row] = scratch[c];
         }
     }
     return true;
 }
+#endif  // host pass
 
 }  // namespace rv32
 }  // namespace dvt
-#endif  // host pass

@@ -722,7 +722,7 @@ std::vector<uint32_t> program_row_map(const Program &prog) {
 
 bool build_aux_host(const ShardMeta &S, const std::vector<AluEvent> &alu, const std::vector<ShaExtEvent> &sha_ext,
                     const std::vector<ShaCmpEvent> &sha_cmp, const std::vector<BigOpEvent> &big, const std::vector<MemInitRow> *mem_rows, int exit_code,
-                    const HostPrep &prep, HostTraces *out, std::string *err) {
+                    const HostPrep &prep, HostTraces *out, std::string *err, BigOpBatches *device_rows) {
     HostTraces &T = *out;
     if (S.n_recs == 0) { if (err) *err = "no cycles to prove"; return false; }
     const bool last = mem_rows != nullptr;
@@ -1033,7 +1033,7 @@ bool build_aux_host(const ShardMeta &S, const std::vector<AluEvent> &alu, const 
         }
     }
     // field / curve precompile chips: one row per call
-    if (!build_bigop_traces(big, S.index, &T, byte_mult.data(), err)) return false;
+    if (!build_bigop_traces(big, S.index, &T, byte_mult.data(), err, device_rows)) return false;
     const uint32_t lp = prep.log_n[RV32_CHIP_PROGRAM];
     T.log_n[RV32_CHIP_PROGRAM] = lp;
     T.main[RV32_CHIP_PROGRAM].assign((size_t)1 << lp, 0);

@@ -236,7 +236,13 @@ struct PermArgs {
     const double *beta_d;  // the same powers as centred doubles [..][4] (f64dot.cuh)
     Fp4 perm_alpha;
     uint32_t log_n;
+    // scratch [PARTS_MAX][4][N] or nullptr.  With it, a short table runs one (row, group of LogUp batches) pair per thread
+    // (perm_rows_parts_kernel): a precompile chip has hundreds of interactions per row and, in most shards, too few rows to
+    // fill the GPU with one thread each.
+    uint32_t *partial = nullptr;
 };
+constexpr int PARTS_MAX = 32;              // groups per chip (constraint groups + LogUp groups) the scratch buffers are sized for
+constexpr uint32_t PARTS_PARALLEL_LOG = 15;  // tables of at most 2^15 rows use the part-parallel launches
 
 template <class Air>
 struct PermRowCtx {
@@ -283,6 +289,31 @@ __global__ void __launch_bounds__(256) perm_rows_kernel(PermArgs a) {
     for (int k = 0; k < 4; k++) a.totals[(size_t)k * ctx.n + row] = ctx.total.c[k].v;   // scanned into phi afterwards
 }
 
+template <class Air, int LP, class Ctx>
+__device__ __forceinline__ void interactions_of_part(Ctx &ctx, int part) {
+    if (part == LP) Air::template interactions_part<LP>(ctx);
+    else if constexpr (LP + 1 < Air::N_LPARTS) interactions_of_part<Air, LP + 1>(ctx, part);
+}
+// grid (row blocks, Air::N_LPARTS): the batch columns of group blockIdx.y, and the group's share of the row total
+template <class Air>
+__global__ void __launch_bounds__(256) perm_rows_parts_kernel(PermArgs a) {
+    size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= ((size_t)1 << a.log_n)) return;
+    PermRowCtx<Air> ctx(a, row);
+    interactions_of_part<Air, 0>(ctx, (int)blockIdx.y);
+#pragma unroll
+    for (int k = 0; k < 4; k++) a.partial[((size_t)blockIdx.y * 4 + k) * ctx.n + row] = ctx.total.c[k].v;
+}
+// out[w] = sum over the parts of partial[part][w]  (field words)
+template <int UNUSED>
+__global__ void __launch_bounds__(256) sum_parts_kernel(const uint32_t *partial, uint32_t nparts, size_t words, uint32_t *out) {
+    size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= words) return;
+    Fp acc = Fp::raw(partial[w]);
+    for (uint32_t p = 1; p < nparts; p++) acc = acc + Fp::raw(partial[(size_t)p * words + w]);
+    out[w] = acc.v;
+}
+
 // ------------------------------------------------------------------ K5: quotient
 struct QuotientArgs {
     const uint32_t *main_lde;  // [MAIN_W][2N]
@@ -304,6 +335,9 @@ struct QuotientArgs {
     // computing x = g w^i (two table gathers, two products) and inverting (x - 1)(x - w^-1) (about sixty products) —
     // the cpu chip's quotient is nine launches.  nullptr: computed in the kernel (the first proof of a height).
     const uint32_t *sel = nullptr;
+    // scratch [PARTS_MAX][2][4][N] or nullptr: with it a short table runs all its groups in ONE launch (quotient_parts_kernel,
+    // blockIdx.y = group, partial quotients summed afterwards) instead of one latency-bound launch per group
+    uint32_t *partial = nullptr;
 };
 
 // the three selectors of one LDE row (what quotient_kernel used to compute inline)
@@ -373,6 +407,39 @@ __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
         if constexpr (PART == 0) o[(size_t)k * n] = q.c[k].v;
         else o[(size_t)k * n] = (Fp::raw(o[(size_t)k * n]) + q.c[k]).v;
     }
+}
+template <class Air, int PART, class F>
+__device__ __forceinline__ Fp4 run_part(F &f, int part) {
+    constexpr int LAST = Air::N_PARTS + (Air::N_INTERACTIONS > 0 ? Air::N_LPARTS : 0) - 1;
+    if (part == PART) return f.template run<PART>();
+    if constexpr (PART < LAST) return run_part<Air, PART + 1>(f, part);
+    return Fp4::zero();
+}
+template <class Air>
+__global__ void __launch_bounds__(256) quotient_parts_kernel(QuotientArgs a) {
+    const size_t m = (size_t)2 << a.log_n;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    QuotAccess ax{a, m, i, (i + 2) & (m - 1)};
+    ConstraintFolder<Air, Fp, QuotAccess> f(ax);
+    f.alpha_pows = a.alpha_pows;
+    f.beta_pows = a.beta_pows;
+    f.alpha_d = a.alpha_d;
+    f.beta_d = a.beta_d;
+    f.perm_alpha = a.perm_alpha;
+    f.cum_over_n = a.cum_over_n;
+    const bool odd = i & 1;
+    const Fp zhinv = odd ? a.zinv_odd : a.zinv_even;
+    if (a.sel) {
+        f.sel_first = Fp::raw(a.sel[i]); f.sel_last = Fp::raw(a.sel[m + i]); f.sel_trans = Fp::raw(a.sel[2 * m + i]);
+    } else {
+        selectors_of_row(a, i, &f.sel_first, &f.sel_last, &f.sel_trans);
+    }
+    Fp4 q = run_part<Air, 0>(f, (int)blockIdx.y) * zhinv;
+    const size_t n = m >> 1;
+    uint32_t *o = a.partial + (size_t)blockIdx.y * 8 * n + (odd ? 4 * n : 0) + (i >> 1);
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[(size_t)k * n] = q.c[k].v;
 }
 #endif  // __HIPCC__
 

@@ -11,14 +11,17 @@ from tests import guests
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("which,log_shard", [("arith", 21), ("bignum", 21), ("hint", 21), ("bignum", 8), ("subword", 21), ("shifts", 8), ("muldiv", 9)])
+# (field_ops / curve_ops / u256_ops: the rows of the precompile chips are built by k0_bigop_rows_kernel, one thread per call,
+# with the byte-table lookups of those rows added to the shard's counts on the device)
+@pytest.mark.parametrize("which,log_shard", [("arith", 21), ("bignum", 21), ("hint", 21), ("bignum", 8), ("subword", 21), ("shifts", 8), ("muldiv", 9),
+                                             ("field_ops", 21), ("field_ops", 9), ("curve_ops", 21), ("curve_ops", 8), ("u256_ops", 21), ("u256_ops", 7)])
 def test_k0_device_traces_equal_host_traces(which, log_shard):
     from dvt_circuits_amd import capi
 
     stdin = []
     if which == "arith":
         elf = guests.arith()[0]
-    elif which in ("shifts", "muldiv"):
+    elif which in ("shifts", "muldiv", "field_ops", "curve_ops", "u256_ops"):
         elf = getattr(guests, which)()[0]
     elif which == "subword":
         elf = guests.subword()[0]

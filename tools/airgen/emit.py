@@ -461,8 +461,9 @@ def emit_c(machine):
 
 
 def emit_rels_header(machine):
-    """C++ tables describing every polynomial identity (dsl.Chip.assert_poly_zero) of the machine, for the host trace
-    builder: it fills the quotient q and the carries w of a row from the row's other cells (rv32_bigops.h)."""
+    """C++ tables describing every polynomial identity (dsl.Chip.assert_poly_zero) of the machine, for the trace
+    builder: it fills the quotient q and the carries w of a row from the row's other cells (rv32_bigops.hip).  DVT_RELS_Q
+    (polyrel.h) places the tables in host memory in the host pass and in device memory in the device pass."""
     up = machine.name.upper()
     out = [f"// GENERATED by tools/airgen (machine '{machine.name}') - do not edit.", "#pragma once", '#include "../polyrel.h"', ""]
     out.append(f"namespace dvt {{ namespace rels_{machine.name} {{")
@@ -482,32 +483,32 @@ def emit_rels_header(machine):
                 if v is None:
                     return "{nullptr, nullptr, 0}"
                 if all(isinstance(x, int) for x in v):
-                    out.append(f"static const uint8_t {pre}_{tag}c[] = {{{', '.join(str(x) for x in v)}}};")
+                    out.append(f"DVT_RELS_Q uint8_t {pre}_{tag}c[] = {{{', '.join(str(x) for x in v)}}};")
                     return f"{{nullptr, {pre}_{tag}c, {len(v)}}}"
-                out.append(f"static const int16_t {pre}_{tag}v[] = {{{', '.join(str(col_of(x)) for x in v)}}};")
+                out.append(f"DVT_RELS_Q int16_t {pre}_{tag}v[] = {{{', '.join(str(col_of(x)) for x in v)}}};")
                 return f"{{{pre}_{tag}v, nullptr, {len(v)}}}"
 
             rows = []
             for ti, (coef, sexpr, a, b) in enumerate(rel.terms[:-1]):      # (the last term is - sel q modulus)
                 rows.append(f"    {{{coef}, {col_of(sexpr)}, {vec(f't{ti}a', a)}, {vec(f't{ti}b', b)}}},")
-            out.append(f"static const PolyTerm {pre}_terms[] = {{")
+            out.append(f"DVT_RELS_Q PolyTerm {pre}_terms[] = {{")
             out += rows
             out.append("};")
             nq = len(rel.q)
-            out.append(f"static const int16_t {pre}_q[] = {{{', '.join(str(col_of(x)) for x in rel.q)}}};")
+            out.append(f"DVT_RELS_Q int16_t {pre}_q[] = {{{', '.join(str(col_of(x)) for x in rel.q)}}};")
             if all(isinstance(b, int) for b in rel.modulus):
                 pinv = pow(sum(b << (8 * i) for i, b in enumerate(rel.modulus)), -1, 1 << (8 * nq))
-                out.append(f"static const uint8_t {pre}_mod[] = {{{', '.join(str(x) for x in rel.modulus)}}};")
-                out.append(f"static const uint8_t {pre}_pinv[] = {{{', '.join(str((pinv >> (8 * i)) & 0xFF) for i in range(nq))}}};")
-                out.append(f"static const int16_t *const {pre}_modv = nullptr;")
+                out.append(f"DVT_RELS_Q uint8_t {pre}_mod[] = {{{', '.join(str(x) for x in rel.modulus)}}};")
+                out.append(f"DVT_RELS_Q uint8_t {pre}_pinv[] = {{{', '.join(str((pinv >> (8 * i)) & 0xFF) for i in range(nq))}}};")
+                out.append(f"DVT_RELS_Q int16_t *const {pre}_modv = nullptr;")
             else:       # the modulus is read from the row (UINT256_MUL): the solver divides
-                out.append(f"static const uint8_t *const {pre}_mod = nullptr, *const {pre}_pinv = nullptr;")
-                out.append(f"static const int16_t {pre}_modv[] = {{{', '.join(str(col_of(x)) for x in rel.modulus)}}};")
-            out.append(f"static const int16_t {pre}_w[] = {{{', '.join(str(col_of(x)) for x in rel.w_lo)}}};")
+                out.append(f"DVT_RELS_Q uint8_t *const {pre}_mod = nullptr, *const {pre}_pinv = nullptr;")
+                out.append(f"DVT_RELS_Q int16_t {pre}_modv[] = {{{', '.join(str(col_of(x)) for x in rel.modulus)}}};")
+            out.append(f"DVT_RELS_Q int16_t {pre}_w[] = {{{', '.join(str(col_of(x)) for x in rel.w_lo)}}};")
             if rel.w_top:
-                out.append(f"static const int16_t {pre}_wb[] = {{{', '.join(str(col_of(x)) for x in rel.w_top)}}};")
-            out.append(f"static const int32_t {pre}_woff[] = {{{', '.join(str(x) for x in rel.w_off)}}};")
-        out.append(f"static const PolyRelDesc {cu}[] = {{")
+                out.append(f"DVT_RELS_Q int16_t {pre}_wb[] = {{{', '.join(str(col_of(x)) for x in rel.w_top)}}};")
+            out.append(f"DVT_RELS_Q int32_t {pre}_woff[] = {{{', '.join(str(x) for x in rel.w_off)}}};")
+        out.append(f"DVT_RELS_Q PolyRelDesc {cu}[] = {{")
         for ri, rel in enumerate(rels):
             pre = f"{cu}_{ri}"
             wb = f"{pre}_wb" if rel.w_top else "nullptr"

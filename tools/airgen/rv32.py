@@ -937,7 +937,7 @@ def build_fp_op():
     for t in w:
         ch.send("byte", [B_U16, 0, t, 0], is_real)
     ch.quotient_parts = 1
-    ch.logup_parts = 2
+    ch.logup_parts = 8      # (groups of LogUp batches: the unit of the part-parallel K4 / K5 launches of short tables, stark.cuh)
     return ch
 
 
@@ -977,7 +977,7 @@ def build_fp2_op():
     for t in w0 + w1:
         ch.send("byte", [B_U16, 0, t, 0], is_real)
     ch.quotient_parts = 1
-    ch.logup_parts = 4
+    ch.logup_parts = 16      # (groups of LogUp batches: the unit of the part-parallel K4 / K5 launches of short tables, stark.cuh)
     return ch
 
 
@@ -1030,7 +1030,7 @@ def build_weierstrass(name, L, Pm, code_add, code_dbl):
     for t in w1 + w2 + w3:
         ch.send("byte", [B_U16, 0, t, 0], is_real)
     ch.quotient_parts = 1
-    ch.logup_parts = 4
+    ch.logup_parts = 16      # (groups of LogUp batches: the unit of the part-parallel K4 / K5 launches of short tables, stark.cuh)
     return ch
 
 
@@ -1093,7 +1093,7 @@ def build_u256_mul():
     for t in w:
         ch.send("byte", [B_U16, 0, t, 0], is_real)
     ch.quotient_parts = 1
-    ch.logup_parts = 2
+    ch.logup_parts = 8      # (groups of LogUp batches: the unit of the part-parallel K4 / K5 launches of short tables, stark.cuh)
     return ch
 
 
