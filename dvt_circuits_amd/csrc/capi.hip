@@ -32,6 +32,11 @@ struct dvt_prover {
     uint32_t exec_threads = 0;        // trace-mode executor threads of the prove pipeline ("exec_threads", 0 = from the host's core count)
     hipStream_t copy_stream = nullptr;            // record uploads overlap the previous shard's kernels
     std::vector<rv32::CycleRec *> pinned;         // pinned staging buffers of 2^log_shard records each, reused across calls
+    // Pinned staging of everything else a shard uploads (auxiliary traces, precompile calls).  Handing the runtime PAGEABLE
+    // memory makes it pin the pages on the fly; when the vectors are freed afterwards the driver quiesces every queue of the
+    // process to drop that mapping - measured as a 20-30 ms stall of the GPU right before phase 1 of a single-shard proof.
+    uint8_t *aux_pinned = nullptr;
+    size_t aux_pinned_bytes = 0;
     std::string err;
     std::mutex mu;
 };
@@ -176,6 +181,7 @@ void dvt_prover_destroy(dvt_prover *p) {
     (void)hipSetDevice(p->eng.device);
     if (p->copy_stream) { (void)hipStreamSynchronize(p->copy_stream); (void)hipStreamDestroy(p->copy_stream); }
     for (auto b : p->pinned) (void)hipHostFree(b);
+    if (p->aux_pinned) (void)hipHostFree(p->aux_pinned);
     p->eng.shutdown();
     delete p;
 }
@@ -518,7 +524,7 @@ static int shard_commit(dvt_prover *p, const dvt_pk *pk, dvt_job *j, ShardJob &s
     const bool time_stages = getenv("DVT_TIME_PREPARE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
-        if (time_stages) fprintf(stderr, "[commit] %s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        if (time_stages) fprintf(stderr, "[commit] %s at %.2f ms (pool misses so far %zu)\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), p->eng.pool.misses);
     };
     // keep the phase-1 results in HBM while they fit (about 3 GB per 2^21-cycle shard); otherwise phase 2 recomputes
     size_t free_b = 0, total_b = 0;
@@ -732,6 +738,25 @@ static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_buf
         HIP_TRY(p, hipMemcpyAsync(s.d_recs, r.buf, s.n_recs * sizeof(rv32::CycleRec), hipMemcpyHostToDevice, p->copy_stream));
         HIP_TRY(p, hipEventRecord(ev, p->copy_stream));
         uint32_t *d_calls[rv32::N_CHIPS] = {};   // per precompile chip: [error word, padding to 16 bytes, the calls]
+        size_t stage_bytes = 0;
+        for (int c = 0; c < m->n_chips; c++) {
+            if (c == RV32_CHIP_CPU || !s.present[c]) continue;
+            stage_bytes += ((r.big.ev[c].empty() ? r.aux.main[c].size() * 4 : r.big.ev[c].size() * sizeof(rv32::BigOpEvent)) + 255) & ~(size_t)255;
+        }
+        if (stage_bytes > p->aux_pinned_bytes) {
+            HIP_TRY(p, hipStreamSynchronize(p->eng.stream));
+            if (p->aux_pinned) HIP_TRY(p, hipHostFree(p->aux_pinned));
+            p->aux_pinned = nullptr; p->aux_pinned_bytes = 0;
+            HIP_TRY(p, hipHostMalloc(&p->aux_pinned, stage_bytes + stage_bytes / 4));
+            p->aux_pinned_bytes = stage_bytes + stage_bytes / 4;
+        }
+        size_t stage_at = 0;
+        auto staged = [&](const void *src, size_t bytes) -> const void * {
+            uint8_t *dst = p->aux_pinned + stage_at;
+            memcpy(dst, src, bytes);
+            stage_at += (bytes + 255) & ~(size_t)255;
+            return dst;
+        };
         for (int c = 0; c < m->n_chips; c++) {
             if (c == RV32_CHIP_CPU || !s.present[c]) continue;
             const std::vector<rv32::BigOpEvent> &calls = r.big.ev[c];
@@ -741,12 +766,13 @@ static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_buf
                 HIP_TRY(p, hipMemsetAsync(s.d_aux[c], 0, words * 4, p->eng.stream));
                 HIP_TRY(p, p->eng.pool.alloc(&d_calls[c], 16 + calls.size() * sizeof(rv32::BigOpEvent)));
                 HIP_TRY(p, hipMemsetAsync(d_calls[c], 0, 16, p->eng.stream));
-                HIP_TRY(p, hipMemcpyAsync(d_calls[c] + 4, calls.data(), calls.size() * sizeof(rv32::BigOpEvent), hipMemcpyHostToDevice, p->eng.stream));
+                HIP_TRY(p, hipMemcpyAsync(d_calls[c] + 4, staged(calls.data(), calls.size() * sizeof(rv32::BigOpEvent)), calls.size() * sizeof(rv32::BigOpEvent),
+                                          hipMemcpyHostToDevice, p->eng.stream));
                 continue;
             }
             size_t words = r.aux.main[c].size();
             HIP_TRY(p, p->eng.pool.alloc(&s.d_aux[c], words * 4));
-            HIP_TRY(p, hipMemcpyAsync(s.d_aux[c], r.aux.main[c].data(), words * 4, hipMemcpyHostToDevice, p->eng.stream));
+            HIP_TRY(p, hipMemcpyAsync(s.d_aux[c], staged(r.aux.main[c].data(), words * 4), words * 4, hipMemcpyHostToDevice, p->eng.stream));
             // byte / program multiplicities stay plain integers until K0 has added the cpu rows' lookups
             if (c != RV32_CHIP_BYTE && c != RV32_CHIP_PROGRAM) HIP_TRY(p, launch_to_internal(p->eng.stream, s.d_aux[c], words));
         }
@@ -757,7 +783,7 @@ static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_buf
                                                   s.d_aux[c], s.log_n[c], s.d_aux[RV32_CHIP_BYTE], d_calls[c]));
             HIP_TRY(p, launch_to_internal(p->eng.stream, s.d_aux[c], words));
         }
-        HIP_TRY(p, hipStreamSynchronize(p->eng.stream));   // r.aux is pageable and about to be released
+        HIP_TRY(p, hipStreamSynchronize(p->eng.stream));   // (the staging buffer is reused by the next shard; the error words below)
         for (int c = 0; c < m->n_chips; c++) {
             if (!d_calls[c]) continue;
             uint32_t row_err = 0;
@@ -801,9 +827,9 @@ static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_buf
             if (!got) { have_prev = false; break; }
             if (rc == DVT_OK) {
                 // (no early return in this scope: the executor threads are joined and the job released below on every path)
-                // the event is re-recorded per shard: wait for this copy before the buffer can be reused / the event re-armed
-                if (hipStreamWaitEvent(p->eng.stream, ev, 0) != hipSuccess || hipEventSynchronize(ev) != hipSuccess)
-                    rc = fail(p, DVT_ERR_DEVICE, "record upload failed");
+                // the event is re-recorded per shard: wait for this copy before the buffer can be reused / the event re-armed.
+                // (the host waits, so the compute stream needs no dependency on the copy stream)
+                if (hipEventSynchronize(ev) != hipSuccess) rc = fail(p, DVT_ERR_DEVICE, "record upload failed");
             }
             have_prev = true;
             prev_buf = r.buf;

@@ -76,7 +76,7 @@ struct Arena {
 struct DevPool {
     std::multimap<size_t, void *> cached;
     std::unordered_map<void *, size_t> live;
-    size_t cached_bytes = 0;
+    size_t cached_bytes = 0, misses = 0;   // (misses: requests that went to hipMalloc)
     hipError_t alloc_bytes(void **out, size_t bytes) {
         bytes = (bytes + 4095) & ~(size_t)4095;
         auto it = cached.lower_bound(bytes);
@@ -87,6 +87,7 @@ struct DevPool {
             cached.erase(it);
             return hipSuccess;
         }
+        misses++;
         hipError_t e = hipMalloc(out, bytes);
         if (e != hipSuccess) {   // give the cache back to the driver and try once more
             (void)hipGetLastError();
@@ -205,7 +206,7 @@ class Engine {
   private:
     char *d_ring = nullptr, *h_ring = nullptr;
     char *h_down = nullptr;  // pinned staging for downloads (roots, opened values, query data): no pageable-memory path
-    static constexpr size_t DOWN_BYTES = 4u << 20;
+    static constexpr size_t DOWN_BYTES = 16u << 20;   // (every download of a proof goes through this pinned buffer: see the note on pageable memory in capi.hip)
     size_t ring_bytes = 0, ring_pos = 0;
     bool fail(const char *fmt, ...);
 };

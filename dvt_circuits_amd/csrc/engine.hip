@@ -1,5 +1,6 @@
 // Shard prover orchestration (host side of K1-K9) — see engine.h.
 #include "engine.h"
+#include <chrono>
 
 #include <cstdarg>
 #include <cstdio>
@@ -311,6 +312,11 @@ bool Engine::commit_main_root(const ProvingKey &pk, const std::vector<ChipTrace>
     HIPCHK(hipSetDevice(device));
     const MachineDesc *m = pk.vk.machine;
     arena.reset();
+    static const bool time_stages = getenv("DVT_TIME_PREPARE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (time_stages) fprintf(stderr, "[commit_main_root] %s at %.2f ms (pool misses so far %zu)\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), pool.misses);
+    };
     size_t need = 0, max_mat_words = 0;
     uint32_t max_log_n = 0;
     for (auto &t : traces) {
@@ -324,6 +330,7 @@ bool Engine::commit_main_root(const ProvingKey &pk, const std::vector<ChipTrace>
     if (arena.cap < need && arena.reserve(need + need / 8) != hipSuccess) { (void)hipGetLastError(); pool.trim(); HIPCHK(arena.reserve(need + need / 8)); }
     uint32_t *d_scratch = arena.alloc<uint32_t>(max_mat_words);
     if (!d_scratch) return fail("commit: device arena exhausted");
+    lap("arena ready");
     std::vector<DevMat> mats;
     bool reuse = false;
     if (keep) {
@@ -334,6 +341,7 @@ bool Engine::commit_main_root(const ProvingKey &pk, const std::vector<ChipTrace>
         keep->valid = false;
     }
     size_t ti = 0;
+    lap("cache decided");
     for (auto &t : traces) {
         const ChipDesc &d = m->chips[t.chip_id];
         uint32_t *lde = nullptr;
@@ -346,6 +354,7 @@ bool Engine::commit_main_root(const ProvingKey &pk, const std::vector<ChipTrace>
             lde = arena.alloc<uint32_t>(((size_t)d.main_w << t.log_n) * 2);
         }
         if (!lde) return fail("commit: device arena exhausted");
+        if (time_stages && ti == 0) lap("first buffer");
         {
             EventTimer t_lde(stream, profile);
             HIPCHK(launch_coset_lde(stream, tabs, const_cast<uint32_t *>(t.d_main), d_scratch, lde, d.main_w, t.log_n, 0));
@@ -357,7 +366,9 @@ bool Engine::commit_main_root(const ProvingKey &pk, const std::vector<ChipTrace>
         }
         mats.push_back({lde, (uint32_t)d.main_w, t.log_n + 1});
         ti++;
+        if (time_stages) lap(d.name);
     }
+    lap("LDEs launched");
     const uint32_t hmax = max_log_n + 1;
     uint32_t *tree = nullptr;
     if (keep && reuse) {
@@ -383,8 +394,10 @@ bool Engine::commit_main_root(const ProvingKey &pk, const std::vector<ChipTrace>
             }
         }
     }
+    lap("tree launched");
     uint32_t rootw[8];
     if (!download(rootw, tree + ((((size_t)2 << hmax) - 1) * 8) - 8, 32)) return false;
+    lap("root downloaded");
     for (int i = 0; i < 8; i++) root->d[i] = Fp::raw(rootw[i]);
     if (keep) { keep->root = *root; keep->valid = true; }
     if (profile) times.commit_main = t_all.stop();

@@ -87,7 +87,7 @@ static const char *curve_op(const MontField<N> &F, const uint32_t *p, const uint
     return nullptr;
 }
 
-// x * y mod m for 256-bit numbers (m = 0: mod 2^256): schoolbook product, then bitwise long division
+// x * y mod m for 256-bit numbers (m = 0: mod 2^256): schoolbook product, then one long division (polyrel.h poly_divmnu)
 static void u256_mulmod(const uint32_t *x, const uint32_t *y, const uint32_t *m, uint32_t *r) {
     uint32_t prod[16] = {0};
     for (int i = 0; i < 8; i++) {
@@ -99,28 +99,11 @@ static void u256_mulmod(const uint32_t *x, const uint32_t *y, const uint32_t *m,
         }
         prod[i + 8] = (uint32_t)carry;
     }
-    bool zero = true;
-    for (int i = 0; i < 8; i++) zero = zero && m[i] == 0;
-    if (zero) { memcpy(r, prod, 32); return; }
-    uint32_t rem[9] = {0};
-    for (int bit = 511; bit >= 0; bit--) {
-        for (int i = 8; i > 0; i--) rem[i] = (rem[i] << 1) | (rem[i - 1] >> 31);
-        rem[0] = (rem[0] << 1) | ((prod[bit >> 5] >> (bit & 31)) & 1);
-        bool ge = rem[8] != 0;
-        if (!ge) {
-            ge = true;
-            for (int i = 7; i >= 0; i--)
-                if (rem[i] != m[i]) { ge = rem[i] > m[i]; break; }
-        }
-        if (ge) {
-            uint64_t borrow = 0;
-            for (int i = 0; i < 9; i++) {
-                const uint64_t d = (uint64_t)rem[i] - (i < 8 ? m[i] : 0) - borrow;
-                rem[i] = (uint32_t)d;
-                borrow = (d >> 32) & 1;
-            }
-        }
-    }
+    int n = 8;
+    while (n > 0 && m[n - 1] == 0) n--;
+    if (n == 0) { memcpy(r, prod, 32); return; }
+    uint32_t q[16], rem[8] = {0};
+    poly_divmnu(q, rem, prod, m, 16, n);
     memcpy(r, rem, 32);
 }
 
@@ -263,12 +246,19 @@ const char *const ROW_ERROR_TEXT[ROW_N_ERRORS] = {
     "curve precompile row: a coordinate is not reduced or the abscissae are equal"};
 #endif
 
-template <class Air, class Row>
+// STAGE_ALL: the whole row by one thread (host).  On the device the row is built in three launches: STAGE_CELLS (one thread
+// per row: everything but the identities' witnesses), the identities (one wave per row, solve_poly_rel_wave below), then
+// STAGE_LOOKUPS (one thread per row: the byte-table lookups of the finished row).
+enum RowStage { STAGE_ALL = 0, STAGE_CELLS = 1, STAGE_LOOKUPS = 2 };
+template <class Air, int STAGE, class Row>
 DVT_HD RowError finish_row(Row &R, const PolyRelDesc *rels, int nrels, const uint32_t *pubs, uint32_t *byte_mult) {
-    for (int i = 0; i < nrels; i++)
-        if (!solve_poly_rel(rels[i], R)) return ROW_NO_WITNESS;
-    LookupCtx<Row> ctx{R, pubs, byte_mult};
-    Air::interactions(ctx);
+    if constexpr (STAGE == STAGE_ALL)
+        for (int i = 0; i < nrels; i++)
+            if (!solve_poly_rel(rels[i], R)) return ROW_NO_WITNESS;
+    if constexpr (STAGE != STAGE_CELLS) {
+        LookupCtx<Row> ctx{R, pubs, byte_mult};
+        Air::interactions(ctx);
+    }
     return ROW_OK;
 }
 
@@ -281,11 +271,12 @@ struct WCols {   // column ids of a short-Weierstrass chip
                            P##x3lt_f_0, P##x3lt_d_0, P##y3lt_f_0, P##y3lt_d_0, P##xne_z_0}
 
 // every cell of the row of call `e` in chip CHIP (the row starts all-zero), its byte-table lookups counted
-template <int CHIP, class Row>
+template <int CHIP, int STAGE, class Row>
 DVT_HD RowError fill_bigop_row(const BigOpEvent &e, uint32_t shard, Row &R, uint32_t *byte_mult) {
     const uint32_t pubs[N_PUBLIC] = {0, 0, 0, shard, 0};   // (the chips read PUB_SHARD only)
     const uint32_t ptrs[2] = {e.a_ptr, e.b_ptr};
     if constexpr (CHIP == RV32_CHIP_FP_OP) {
+        if constexpr (STAGE != STAGE_LOOKUPS) {
         const int op = (int)(e.code - SYS_BLS12381_FP_ADD);
         R.put(RV32_FP_OP_is_real, 1); R.put(op == 0 ? RV32_FP_OP_is_add : op == 1 ? RV32_FP_OP_is_sub : RV32_FP_OP_is_mul, 1);
         R.put(RV32_FP_OP_clk, e.clk);
@@ -296,8 +287,10 @@ DVT_HD RowError fill_bigop_row(const BigOpEvent &e, uint32_t shard, Row &R, uint
             mem_meta(R, RV32_FP_OP_mx_sh_0, k, e.a_sh[k], e.a_ts[k], shard, e.clk + 3);
         }
         if (!fill_lt(R, RV32_FP_OP_rlt_f_0, RV32_FP_OP_rlt_d_0, RV32_FP_OP_r_0, 48, ConstMod{rels_rv32::fp_op_0_mod})) return ROW_FP_NOT_REDUCED;
-        return finish_row<air_rv32::FpOp>(R, rels_rv32::fp_op, rels_rv32::fp_op_n, pubs, byte_mult);
+        }
+        return finish_row<air_rv32::FpOp, STAGE>(R, rels_rv32::fp_op, rels_rv32::fp_op_n, pubs, byte_mult);
     } else if constexpr (CHIP == RV32_CHIP_U256_MUL) {
+        if constexpr (STAGE != STAGE_LOOKUPS) {
         R.put(RV32_U256_MUL_is_real, 1); R.put(RV32_U256_MUL_clk, e.clk);
         put_bytes(R, RV32_U256_MUL_xp_0, &ptrs[0], 1); put_bytes(R, RV32_U256_MUL_yp_0, &ptrs[1], 1);
         put_bytes(R, RV32_U256_MUL_x_0, e.a, 8); put_bytes(R, RV32_U256_MUL_y_0, e.b, 8); put_bytes(R, RV32_U256_MUL_m_0, e.b + 8, 8); put_bytes(R, RV32_U256_MUL_r_0, e.r, 8);
@@ -315,8 +308,10 @@ DVT_HD RowError fill_bigop_row(const BigOpEvent &e, uint32_t shard, Row &R, uint
             }
             if (!fill_lt(R, RV32_U256_MUL_rlt_f_0, RV32_U256_MUL_rlt_d_0, RV32_U256_MUL_r_0, 32, RowMod<Row>{R, RV32_U256_MUL_m_0})) return ROW_U256_NOT_BELOW;
         }
-        return finish_row<air_rv32::U256Mul>(R, rels_rv32::u256_mul, rels_rv32::u256_mul_n, pubs, byte_mult);
+        }
+        return finish_row<air_rv32::U256Mul, STAGE>(R, rels_rv32::u256_mul, rels_rv32::u256_mul_n, pubs, byte_mult);
     } else if constexpr (CHIP == RV32_CHIP_FP2_OP) {
+        if constexpr (STAGE != STAGE_LOOKUPS) {
         const int op = (int)(e.code - SYS_BLS12381_FP2_ADD);
         R.put(RV32_FP2_OP_is_real, 1); R.put(op == 0 ? RV32_FP2_OP_is_add : op == 1 ? RV32_FP2_OP_is_sub : RV32_FP2_OP_is_mul, 1);
         R.put(RV32_FP2_OP_clk, e.clk);
@@ -330,9 +325,11 @@ DVT_HD RowError fill_bigop_row(const BigOpEvent &e, uint32_t shard, Row &R, uint
         }
         if (!fill_lt(R, RV32_FP2_OP_r0lt_f_0, RV32_FP2_OP_r0lt_d_0, RV32_FP2_OP_r0_0, 48, ConstMod{rels_rv32::fp2_op_0_mod}) ||
             !fill_lt(R, RV32_FP2_OP_r1lt_f_0, RV32_FP2_OP_r1lt_d_0, RV32_FP2_OP_r1_0, 48, ConstMod{rels_rv32::fp2_op_0_mod})) return ROW_FP2_NOT_REDUCED;
-        return finish_row<air_rv32::Fp2Op>(R, rels_rv32::fp2_op, rels_rv32::fp2_op_n, pubs, byte_mult);
+        }
+        return finish_row<air_rv32::Fp2Op, STAGE>(R, rels_rv32::fp2_op, rels_rv32::fp2_op_n, pubs, byte_mult);
     } else {
         constexpr bool is_bls = CHIP == RV32_CHIP_BLS_G1;
+        if constexpr (STAGE != STAGE_LOOKUPS) {
         const WCols C = is_bls ? DVT_WCOLS(RV32_BLS_G1_) : DVT_WCOLS(RV32_SECP_K1_);
         constexpr int L = is_bls ? 48 : 32, W = L / 4;     // bytes / words per coordinate
         const ConstMod mod{is_bls ? rels_rv32::bls_g1_0_mod : rels_rv32::secp_k1_0_mod};
@@ -350,35 +347,193 @@ DVT_HD RowError fill_bigop_row(const BigOpEvent &e, uint32_t shard, Row &R, uint
                   fill_lt(R, C.x3lt_f, C.x3lt_d, C.x3, L, mod) && fill_lt(R, C.y3lt_f, C.y3lt_d, C.y3, L, mod);
         if (add) ok = ok && fill_lt(R, C.x2lt_f, C.x2lt_d, C.x2, L, mod) && fill_lt(R, C.y2lt_f, C.y2lt_d, C.y2, L, mod) && fill_differ(R, C.xne_z, C.x1, C.x2, L);
         if (!ok) return ROW_CURVE_BAD;
-        if constexpr (is_bls) return finish_row<air_rv32::BlsG1>(R, rels_rv32::bls_g1, rels_rv32::bls_g1_n, pubs, byte_mult);
-        else return finish_row<air_rv32::SecpK1>(R, rels_rv32::secp_k1, rels_rv32::secp_k1_n, pubs, byte_mult);
+        }
+        if constexpr (is_bls) return finish_row<air_rv32::BlsG1, STAGE>(R, rels_rv32::bls_g1, rels_rv32::bls_g1_n, pubs, byte_mult);
+        else return finish_row<air_rv32::SecpK1, STAGE>(R, rels_rv32::secp_k1, rels_rv32::secp_k1_n, pubs, byte_mult);
     }
 }
 }  // namespace
 
-// ------------------------------------------------------------------ device: one thread per call
+// ------------------------------------------------------------------ device: K0 of the precompile chips
 #if defined(__HIPCC__)
-template <int CHIP>
+// The identities of one row by one wave: coefficient k of V, of low * m^-1 and of q * m belongs to lane k mod 64 (operand
+// bytes in LDS); the carry sweeps (base-256 digits of V, of the quotient, the carries W_k) are short serial loops of lane 0
+// over LDS.  Same results as solve_poly_rel (polyrel.h), which one thread per row runs out of scratch memory — 50 k
+// multiply-adds per G1 row through ~5 KB of private arrays took 25 ms for 13 k rows; this takes well under one.
+struct RelShared {
+    int32_t a[POLY_MAX_K], b[POLY_MAX_K], s[POLY_MAX_K], w[POLY_MAX_K];
+    long long c[POLY_MAX_K];
+    uint8_t low[POLY_MAX_K + 8], q[POLY_MAX_K], mod[POLY_MAX_K];
+    int ok;
+};
+__device__ static void load_vec(const PolyVec &v, const DevRow &row, int32_t *o, int lane) {
+    for (int i = lane; i < v.len; i += 64) o[i] = v.cols ? (int32_t)row.get(v.cols[i]) : (int32_t)v.cst[i];
+}
+__device__ static bool solve_poly_rel_wave(const PolyRelDesc &d, DevRow &row, RelShared &S, int lane) {
+    if (d.K > POLY_MAX_K) return false;
+    for (int k = lane; k < POLY_MAX_K; k += 64) S.c[k] = 0;
+    if (lane == 0) S.ok = 1;
+    __syncthreads();
+    for (int t = 0; t < d.n_terms; t++) {
+        const PolyTerm &tm = d.terms[t];
+        if (!row.get(tm.sel_col)) continue;     // (the same cell for every lane)
+        load_vec(tm.a, row, S.a, lane);
+        if (tm.b.len) load_vec(tm.b, row, S.b, lane);
+        __syncthreads();
+        const int la = tm.a.len, lb = tm.b.len;
+        if (lb == 0) {
+            for (int k = lane; k < la; k += 64) S.c[k] += (long long)tm.coef * S.a[k];
+        } else {
+            for (int k = lane; k < la + lb - 1; k += 64) {
+                const int i0 = k - lb + 1 > 0 ? k - lb + 1 : 0, i1 = k < la - 1 ? k : la - 1;
+                int32_t acc = 0;
+                for (int i = i0; i <= i1; i++) acc += S.a[i] * S.b[k - i];
+                S.c[k] += (long long)tm.coef * acc;
+            }
+        }
+        __syncthreads();
+    }
+    for (int j = lane; j < d.nmod; j += 64) S.mod[j] = d.modv ? (uint8_t)row.get(d.modv[j]) : d.mod[j];
+    __syncthreads();
+    if (!d.modv) {
+        if (lane == 0) {
+            long long t = 0;
+            for (int k = 0; k < d.nq; k++) {
+                if (k < d.K) t += S.c[k];
+                const uint8_t lo = (uint8_t)(t & 255);
+                S.low[k] = lo;
+                t = (t - lo) / 256;
+            }
+        }
+        __syncthreads();
+        for (int k = lane; k < d.nq; k += 64) {
+            int32_t acc = 0;
+            for (int i = 0; i <= k; i++) acc += (int32_t)S.low[i] * (int32_t)d.pinv[k - i];
+            S.s[k] = acc;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            uint64_t carry = 0;
+            for (int k = 0; k < d.nq; k++) {
+                const uint64_t v = carry + (uint32_t)S.s[k];
+                S.q[k] = (uint8_t)(v & 255);
+                carry = v >> 8;
+            }
+        }
+    } else if (lane == 0) {
+        // the modulus comes from the row and may be even: all K digits of V, then one long division (lane 0; UINT256_MUL only)
+        long long t = 0;
+        for (int k = 0; k < d.K; k++) {
+            t += S.c[k];
+            const uint8_t lo = (uint8_t)(t & 255);
+            S.low[k] = lo;
+            t = (t - lo) / 256;
+        }
+        int nm = d.nmod;
+        while (nm > 0 && S.mod[nm - 1] == 0) nm--;
+        bool ok = t == 0 && nm > 0;
+        uint32_t u[POLY_MAX_K / 4 + 2] = {0}, v[POLY_MAX_K / 4 + 2] = {0}, qw[POLY_MAX_K / 4 + 2] = {0}, rw[POLY_MAX_K / 4 + 2] = {0};
+        if (ok) {
+            for (int k = 0; k < d.K; k++) u[k >> 2] |= (uint32_t)S.low[k] << (8 * (k & 3));
+            for (int k = 0; k < nm; k++) v[k >> 2] |= (uint32_t)S.mod[k] << (8 * (k & 3));
+            const int mu = (d.K + 3) / 4, nv = (nm + 3) / 4;
+            if (mu >= nv) poly_divmnu(qw, rw, u, v, mu, nv);
+            else for (int k = 0; k < mu; k++) rw[k] = u[k];
+            for (int k = 0; k < nv; k++) ok = ok && rw[k] == 0;
+            for (int k = 0; k < d.nq; k++) S.q[k] = 0;
+            for (int k = 0; k < 4 * (mu >= nv ? mu - nv + 1 : 0); k++) {
+                const uint8_t digit = (uint8_t)(qw[k >> 2] >> (8 * (k & 3)));
+                if (!digit) continue;
+                if (k >= d.nq) { ok = false; break; }
+                S.q[k] = digit;
+            }
+        }
+        if (!ok) S.ok = 0;
+    }
+    __syncthreads();
+    if (!S.ok) return false;
+    for (int k = lane; k < d.nq; k += 64) row.put(d.q[k], S.q[k]);
+    for (int k = lane; k < d.nq + d.nmod - 1 && k < POLY_MAX_K; k += 64) {
+        const int i0 = k - d.nmod + 1 > 0 ? k - d.nmod + 1 : 0, i1 = k < d.nq - 1 ? k : d.nq - 1;
+        int32_t acc = 0;
+        for (int i = i0; i <= i1; i++) acc += (int32_t)S.q[i] * (int32_t)S.mod[k - i];
+        S.c[k] -= acc;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        long long W = 0;
+        bool ok = true;
+        for (int k = 0; k + 1 < d.K; k++) {
+            const long long v = S.c[k] + W;
+            if (v & 255) { ok = false; break; }
+            W = v / 256;
+            const long long wv = W + d.w_off[k];
+            if (wv < 0 || wv >= (d.wb ? 131072 : 65536)) { ok = false; break; }
+            S.w[k] = (int32_t)wv;
+        }
+        if (ok && S.c[d.K - 1] + W != 0) ok = false;
+        if (!ok) S.ok = 0;
+    }
+    __syncthreads();
+    if (!S.ok) return false;
+    for (int k = lane; k + 1 < d.K; k += 64) {
+        row.put(d.w[k], (uint32_t)(S.w[k] & 0xffff));
+        if (d.wb) row.put(d.wb[k], (uint32_t)(S.w[k] >> 16));
+    }
+    __syncthreads();
+    return true;
+}
+
+template <int CHIP> struct ChipRels;
+template <> struct ChipRels<RV32_CHIP_FP_OP> { static __device__ const PolyRelDesc *get(int *n) { *n = rels_rv32::fp_op_n; return rels_rv32::fp_op; } };
+template <> struct ChipRels<RV32_CHIP_FP2_OP> { static __device__ const PolyRelDesc *get(int *n) { *n = rels_rv32::fp2_op_n; return rels_rv32::fp2_op; } };
+template <> struct ChipRels<RV32_CHIP_BLS_G1> { static __device__ const PolyRelDesc *get(int *n) { *n = rels_rv32::bls_g1_n; return rels_rv32::bls_g1; } };
+template <> struct ChipRels<RV32_CHIP_SECP_K1> { static __device__ const PolyRelDesc *get(int *n) { *n = rels_rv32::secp_k1_n; return rels_rv32::secp_k1; } };
+template <> struct ChipRels<RV32_CHIP_U256_MUL> { static __device__ const PolyRelDesc *get(int *n) { *n = rels_rv32::u256_mul_n; return rels_rv32::u256_mul; } };
+
+// one thread per call: STAGE_CELLS before the identities, STAGE_LOOKUPS after them
+template <int CHIP, int STAGE>
 __global__ void __launch_bounds__(64) k0_bigop_rows_kernel(const BigOpEvent *ev, uint32_t n_ev, uint32_t shard, uint32_t *main, uint32_t log_n, uint32_t *byte_mult,
                                                            uint32_t *err) {
     const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_ev) return;
     DevRow R{main, (size_t)1 << log_n, row};
-    const RowError e = fill_bigop_row<CHIP>(ev[row], shard, R, byte_mult);
+    const RowError e = fill_bigop_row<CHIP, STAGE>(ev[row], shard, R, byte_mult);
     if (e != ROW_OK) atomicMax(err, (uint32_t)e);
 }
+// one wave per call: q and the carries of every identity of the chip
+template <int CHIP>
+__global__ void __launch_bounds__(64) k0_bigop_rels_kernel(uint32_t n_ev, uint32_t *main, uint32_t log_n, uint32_t *err) {
+    __shared__ RelShared S;
+    const uint32_t row = blockIdx.x;
+    if (row >= n_ev) return;
+    DevRow R{main, (size_t)1 << log_n, row};
+    int nrels = 0;
+    const PolyRelDesc *rels = ChipRels<CHIP>::get(&nrels);
+    for (int i = 0; i < nrels; i++)
+        if (!solve_poly_rel_wave(rels[i], R, S, (int)threadIdx.x)) {
+            if (threadIdx.x == 0) atomicMax(err, (uint32_t)ROW_NO_WITNESS);
+            return;     // (the whole wave: S.ok is shared)
+        }
+}
 
+template <int CHIP>
+static void launch_chip_rows(hipStream_t st, const BigOpEvent *d_ev, uint32_t n_ev, uint32_t shard, uint32_t *d_main, uint32_t log_n, uint32_t *d_byte_mult, uint32_t *d_err) {
+    const unsigned blocks = (n_ev + 63) / 64;
+    k0_bigop_rows_kernel<CHIP, STAGE_CELLS><<<blocks, 64, 0, st>>>(d_ev, n_ev, shard, d_main, log_n, d_byte_mult, d_err);
+    k0_bigop_rels_kernel<CHIP><<<n_ev, 64, 0, st>>>(n_ev, d_main, log_n, d_err);
+    k0_bigop_rows_kernel<CHIP, STAGE_LOOKUPS><<<blocks, 64, 0, st>>>(d_ev, n_ev, shard, d_main, log_n, d_byte_mult, d_err);
+}
 hipError_t launch_k0_bigop_rows(hipStream_t st, int chip, const BigOpEvent *d_ev, uint32_t n_ev, uint32_t shard, uint32_t *d_main, uint32_t log_n,
                                 uint32_t *d_byte_mult, uint32_t *d_err) {
     if (!n_ev) return hipSuccess;
     if (((size_t)1 << log_n) < n_ev) return hipErrorInvalidValue;
-    const unsigned blocks = (n_ev + 63) / 64;
     switch (chip) {
-    case RV32_CHIP_FP_OP: k0_bigop_rows_kernel<RV32_CHIP_FP_OP><<<blocks, 64, 0, st>>>(d_ev, n_ev, shard, d_main, log_n, d_byte_mult, d_err); break;
-    case RV32_CHIP_FP2_OP: k0_bigop_rows_kernel<RV32_CHIP_FP2_OP><<<blocks, 64, 0, st>>>(d_ev, n_ev, shard, d_main, log_n, d_byte_mult, d_err); break;
-    case RV32_CHIP_BLS_G1: k0_bigop_rows_kernel<RV32_CHIP_BLS_G1><<<blocks, 64, 0, st>>>(d_ev, n_ev, shard, d_main, log_n, d_byte_mult, d_err); break;
-    case RV32_CHIP_SECP_K1: k0_bigop_rows_kernel<RV32_CHIP_SECP_K1><<<blocks, 64, 0, st>>>(d_ev, n_ev, shard, d_main, log_n, d_byte_mult, d_err); break;
-    case RV32_CHIP_U256_MUL: k0_bigop_rows_kernel<RV32_CHIP_U256_MUL><<<blocks, 64, 0, st>>>(d_ev, n_ev, shard, d_main, log_n, d_byte_mult, d_err); break;
+    case RV32_CHIP_FP_OP: launch_chip_rows<RV32_CHIP_FP_OP>(st, d_ev, n_ev, shard, d_main, log_n, d_byte_mult, d_err); break;
+    case RV32_CHIP_FP2_OP: launch_chip_rows<RV32_CHIP_FP2_OP>(st, d_ev, n_ev, shard, d_main, log_n, d_byte_mult, d_err); break;
+    case RV32_CHIP_BLS_G1: launch_chip_rows<RV32_CHIP_BLS_G1>(st, d_ev, n_ev, shard, d_main, log_n, d_byte_mult, d_err); break;
+    case RV32_CHIP_SECP_K1: launch_chip_rows<RV32_CHIP_SECP_K1>(st, d_ev, n_ev, shard, d_main, log_n, d_byte_mult, d_err); break;
+    case RV32_CHIP_U256_MUL: launch_chip_rows<RV32_CHIP_U256_MUL>(st, d_ev, n_ev, shard, d_main, log_n, d_byte_mult, d_err); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -427,11 +582,11 @@ bool build_bigop_traces(const std::vector<BigOpEvent> &big, uint32_t shard, Host
             RowRef R{scratch.data()};
             RowError re = ROW_OK;
             switch (chip) {
-            case RV32_CHIP_FP_OP: re = fill_bigop_row<RV32_CHIP_FP_OP>(e, shard, R, byte_mult); break;
-            case RV32_CHIP_FP2_OP: re = fill_bigop_row<RV32_CHIP_FP2_OP>(e, shard, R, byte_mult); break;
-            case RV32_CHIP_BLS_G1: re = fill_bigop_row<RV32_CHIP_BLS_G1>(e, shard, R, byte_mult); break;
-            case RV32_CHIP_SECP_K1: re = fill_bigop_row<RV32_CHIP_SECP_K1>(e, shard, R, byte_mult); break;
-            default: re = fill_bigop_row<RV32_CHIP_U256_MUL>(e, shard, R, byte_mult); break;
+            case RV32_CHIP_FP_OP: re = fill_bigop_row<RV32_CHIP_FP_OP, STAGE_ALL>(e, shard, R, byte_mult); break;
+            case RV32_CHIP_FP2_OP: re = fill_bigop_row<RV32_CHIP_FP2_OP, STAGE_ALL>(e, shard, R, byte_mult); break;
+            case RV32_CHIP_BLS_G1: re = fill_bigop_row<RV32_CHIP_BLS_G1, STAGE_ALL>(e, shard, R, byte_mult); break;
+            case RV32_CHIP_SECP_K1: re = fill_bigop_row<RV32_CHIP_SECP_K1, STAGE_ALL>(e, shard, R, byte_mult); break;
+            default: re = fill_bigop_row<RV32_CHIP_U256_MUL, STAGE_ALL>(e, shard, R, byte_mult); break;
             }
             if (re != ROW_OK) { if (err) *err = ROW_ERROR_TEXT[re]; return false; }
             uint32_t *dst = T.main[chip].data();
