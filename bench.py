@@ -26,6 +26,9 @@ Extra objects on the JSON line (rank 0 prints exactly one line):
   roofline      the dominant HBM-classified kernel family, K1 coset LDE: algorithmic bytes (12 B per trace element:
                 read N, write 2N words per column) / summed duration of its launches inside one prove, HIP events on
                 the prover's own stream; "alu_bound_exception" carries the Poseidon2 commitment kernels (K2/K3)
+  reference_example  BASELINE configs[1] taken literally (tools/bench_reference_guest.py): one proof of the reference's example
+                input through the re-stated finalization guest - ms per whole prove() call, proofs/hour with one and with three
+                prover handles on the GPU
   cpu_baseline  the oracle's CPU prover (tests/_oracle_prover.py over oracle/*.c, OpenMP) on two bounded samples of the
                 same guest (smaller iteration constants), production parameters; value = marginal cycles/s
 """
@@ -147,6 +150,7 @@ def main():
     ap.add_argument("--cpu-sizes", type=int, nargs=2, default=[30, 95], help="guest iteration constants of the two CPU-baseline samples "
                     "(95 = a little over 1 M cycles: the fixed costs are then below a fifth of the larger sample)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-example", action="store_true", help="skip the extra object with BASELINE configs[1] taken literally")
     args = ap.parse_args()
     global SHA_PRECOMPILES, CURVE_PRECOMPILES
     SHA_PRECOMPILES = args.sha_precompiles
@@ -391,6 +395,12 @@ def main():
         },
     }
     if rank == 0:
+        if not args.no_reference_example and world == 1 and not args.batch:
+            # BASELINE configs[1] taken literally (single shard, the reference's example input through the re-stated
+            # finalization guest, tests/guests_finalization.py): whole-call latency, and proofs/hour with three handles
+            from tools import bench_reference_guest
+
+            out["reference_example"] = bench_reference_guest.measure(reps=5, handles=3)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(stdin_buf, args.cpu_sizes)
         print(json.dumps(out), flush=True)

@@ -582,7 +582,7 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
         uint32_t *totals, *scan_scratch;
         ALLOC(totals, uint32_t, 4 * s.n);
         PermArgs pa{s.main, s.prep, d_pub, s.perm, totals, d_beta, d_beta_f64, perm_alpha, s.log_n};
-        if (s.log_n <= PARTS_PARALLEL_LOG) pa.partial = d_parts;
+        if (s.log_n <= PARTS_PARALLEL_LOG) pa.partial = d_parts;   // (tall tables: measured, no gain - 68.14 against 68.09 M cycles/s)
         HIPCHK(s.d->launch_perm(stream, pa));
         ALLOC(scan_scratch, uint32_t, prefix_sum_scratch_words(4, s.n));
         HIPCHK(launch_prefix_sum_columns(stream, totals, 4, s.n, scan_scratch));
@@ -671,12 +671,28 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
         struct Pending { size_t off; uint32_t width; Fp4 scale; std::vector<Fp4> *local, *next; };
         std::vector<Pending> pending;
         size_t res_off = 0;
+        // the column pointers of every matrix in ONE upload (a small host-to-device copy between two kernels costs a pipeline
+        // bubble of tens of microseconds, and there are ~40 matrices in a shard with precompile chips)
+        std::vector<uint64_t> all_ptrs;
+        {
+            auto add = [&](const uint32_t *base, uint32_t width, size_t n) {
+                for (uint32_t c = 0; c < width; c++) all_ptrs.push_back((uint64_t)(uintptr_t)(base + (size_t)c * n));
+            };
+            for (auto &s : cs) {
+                if (s.d->prep_w) add(s.prep, s.d->prep_w, s.n);
+                add(s.main, s.d->main_w, s.n);
+                if (s.d->perm_ext_w) add(s.perm, 4 * s.d->perm_ext_w, s.n);
+                for (int c = 0; c < 2; c++) add(s.quot + (size_t)4 * c * s.n, 4, s.n);
+            }
+        }
+        auto d_all_cols = reinterpret_cast<const uint32_t *const *>(upload(all_ptrs.data(), all_ptrs.size() * 8));
+        if (!d_all_cols) return false;
+        size_t cols_at = 0;
         auto open_matrix = [&](const uint32_t *base, uint32_t width, const ChipState &s, Fp4 scale, std::vector<Fp4> *local,
                                std::vector<Fp4> *next) -> bool {
-            std::vector<uint64_t> ptrs(width);
-            for (uint32_t c = 0; c < width; c++) ptrs[c] = (uint64_t)(uintptr_t)(base + (size_t)c * s.n);
-            auto d_cols = reinterpret_cast<const uint32_t *const *>(upload(ptrs.data(), width * 8));
-            if (!d_cols) return false;
+            if (cols_at + width > all_ptrs.size() || all_ptrs[cols_at] != (uint64_t)(uintptr_t)base) return fail("prove: internal error, opening order");
+            const uint32_t *const *d_cols = d_all_cols + cols_at;
+            cols_at += width;
             HIPCHK(launch_open_columns(stream, d_cols, width, s.log_n, d_w, d_partial, d_res + res_off));
             pending.push_back({res_off, width, scale, local, next});
             res_off += (size_t)width * 2;
@@ -753,15 +769,18 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
             for (int k = 0; k < 4; k++) apow_d[4 * c + k] = centred_canonical(apow[c].c[k]);
         const double *d_apow = reinterpret_cast<const double *>(upload(apow_d.data(), apow_d.size() * sizeof(double)));
         if (!d_apow) return false;
+        // pointer tables of every height in one upload (see the openings above), then the launches
+        std::vector<uint64_t> all_ptrs;
+        std::vector<size_t> ptr_at(hmax + 1, 0);
+        std::vector<Fp4> sz_all_h(hmax + 1, Fp4::zero()), sz_two_h(hmax + 1, Fp4::zero());
         for (uint32_t h = 1; h <= hmax; h++) {
             auto &cols = cols_by_h[h];
-            if (cols.empty()) continue;
-            std::vector<uint64_t> ptrs(cols.size());
+            ptr_at[h] = all_ptrs.size();
             Fp4 sz_all = Fp4::zero(), sz_two = Fp4::zero();
             for (size_t c = 0; c < cols.size(); c++) {
                 const ColRef &r = cols[c];
                 const TreeMat &tmx = tree_mats[r.tree][r.mat];
-                ptrs[c] = (uint64_t)(uintptr_t)(tmx.lde + ((size_t)r.col << h));
+                all_ptrs.push_back((uint64_t)(uintptr_t)(tmx.lde + ((size_t)r.col << h)));
                 const ChipOpening &o = pf.chips[r.chip_pos];
                 const std::vector<Fp4> &loc = r.tree == 0 ? o.prep_l : r.tree == 1 ? o.main_l : r.tree == 2 ? o.perm_l : o.quot;
                 sz_all += apow[c] * loc[r.col];
@@ -770,11 +789,16 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
                     sz_two += apow[c] * nx[r.col];
                 }
             }
-            auto d_cols = reinterpret_cast<const uint32_t *const *>(upload(ptrs.data(), ptrs.size() * 8));
-            if (!d_cols) return false;
+            sz_all_h[h] = sz_all; sz_two_h[h] = sz_two;
+        }
+        auto d_all_cols = reinterpret_cast<const uint32_t *const *>(upload(all_ptrs.data(), all_ptrs.size() * 8));
+        if (!d_all_cols) return false;
+        for (uint32_t h = 1; h <= hmax; h++) {
+            auto &cols = cols_by_h[h];
+            if (cols.empty()) continue;
             ALLOC(ro[h], Fp4, (size_t)1 << h);
             Fp4 zeta_next = zeta * two_adic_generator(h - 1);
-            HIPCHK(launch_reduced_opening(stream, tabs, d_cols, n_two_by_h[h], (uint32_t)cols.size(), h, d_apow, sz_all, sz_two,
+            HIPCHK(launch_reduced_opening(stream, tabs, d_all_cols + ptr_at[h], n_two_by_h[h], (uint32_t)cols.size(), h, d_apow, sz_all_h[h], sz_two_h[h],
                                           zeta, zeta_next, apow[cols.size()], ro[h]));
         }
     }

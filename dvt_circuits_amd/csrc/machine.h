@@ -57,7 +57,7 @@ hipError_t launch_perm_t(hipStream_t st, const PermArgs &a) {
     if (Air::N_INTERACTIONS == 0) return hipSuccess;
     size_t n = (size_t)1 << a.log_n;
     if constexpr (Air::N_LPARTS > 1 && Air::N_LPARTS <= PARTS_MAX) {
-        if (a.partial && a.log_n <= PARTS_PARALLEL_LOG) {
+        if (a.partial) {
             perm_rows_parts_kernel<Air><<<dim3((unsigned)((n + 255) / 256), Air::N_LPARTS), 256, 0, st>>>(a);
             sum_parts_kernel<0><<<(unsigned)((4 * n + 255) / 256), 256, 0, st>>>(a.partial, Air::N_LPARTS, 4 * n, a.totals);
             return hipGetLastError();

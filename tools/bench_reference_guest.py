@@ -18,11 +18,10 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 
 
-def main():
+def measure(reps=5, handles=1):
     from dvt_circuits_amd import capi
     from tests import guests_finalization as gf
 
-    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     example = open(os.path.join(ROOT, "tests", "golden", "finalization_example.json"), "rb").read()
     buf = capi.stdin_from_json("finalization", example)
     elf = gf.finalization(nmax=8, kmax=8)
@@ -40,7 +39,6 @@ def main():
     capi.execute(elf, [buf])
     t_exec = time.perf_counter() - t
     batch = None
-    handles = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     if handles > 1:
         import threading
 
@@ -66,13 +64,20 @@ def main():
         for q, k in zip(provers, keys):
             q.pk_free(k)
             q.close()
-    print(json.dumps({"workload": "reference examples/finalization_test.json (n = 3, k = 2) through the re-stated finalization guest (no pairings)",
+    result = ({"workload": "reference examples/finalization_test.json (n = 3, k = 2) through the re-stated finalization guest (no pairings)",
                       "guest_cycles": rep["cycles"], "shards": n, "public_values_bytes": len(pv), "proof_bytes": len(proof),
                       "ms_per_proof": 1000 * dt, "proofs_per_hour": 3600 / dt, "guest_cycles_per_s": rep["cycles"] / dt,
                       "execute_only_ms": 1000 * t_exec, "concurrent_handles": batch,
-                      "chip_heights_by_id": {str(c["chip_id"]): [int(c["main"].shape[1]), int(c["main"].shape[0])] for c in chips}}))
+                      "chip_heights_by_id": {str(c["chip_id"]): [int(c["main"].shape[1]), int(c["main"].shape[0])] for c in chips}})
     p.pk_free(pk)
     p.close()
+    return result
+
+
+def main():
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    handles = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    print(json.dumps(measure(reps, handles)))
 
 
 if __name__ == "__main__":
