@@ -453,7 +453,7 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
     std::vector<ChipRef> refs;
     size_t max_mat_words = 0;
     uint32_t max_log_n = 0;
-    size_t need = 0;
+    size_t need = 0, max_open_cols = 8;
     for (auto &t : traces) {
         if (t.chip_id < 0 || t.chip_id >= m->n_chips) return fail("prove: chip id %d out of range", t.chip_id);
         if (!cs.empty() && t.chip_id <= cs.back().id) return fail("prove: chip traces must be sorted by chip id");
@@ -471,6 +471,7 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
         size_t w = std::max<size_t>({(size_t)s.d->main_w, (size_t)4 * s.d->perm_ext_w, 4});
         max_mat_words = std::max(max_mat_words, w * s.n);
         need += (size_t)(s.d->main_w * 2 + 4 * s.d->perm_ext_w * 3 + 4 + 8 * 3) * s.n * 4 + 16 * 256;
+        max_open_cols = std::max<size_t>(max_open_cols, (size_t)s.d->main_w + 4 * s.d->perm_ext_w + s.d->prep_w);
     }
     if (cs.empty()) return fail("prove: no chips");
     for (auto &pc : pk.prep) {
@@ -493,6 +494,7 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
     need += ((size_t)1 << hmax) * 16 * 4 + 2 * tree_words(hmax) * 4;
     need += ((size_t)1 << max_log_n) * 16 * 3 + (64u << 20);
     need += ((size_t)PARTS_MAX * 32) << std::min(max_log_n, PARTS_PARALLEL_LOG);
+    need += (size_t)OPEN_MAX_ROW_BLOCKS * max_open_cols * 2 * sizeof(Fp4);   // K6 partial sums
     if (arena.cap < need && arena.reserve(need + need / 8) != hipSuccess) { (void)hipGetLastError(); pool.trim(); HIPCHK(arena.reserve(need + need / 8)); }
 #define ALLOC(var, T, count)                                                        \
     do {                                                                            \
@@ -660,7 +662,7 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
         Fp4 *d_w;
         ALLOC(d_w, Fp4, (size_t)1 << max_log_n);
         size_t max_cols = 8;
-        for (auto &s : cs) max_cols = std::max<size_t>({max_cols, (size_t)s.d->main_w, (size_t)4 * s.d->perm_ext_w, (size_t)s.d->prep_w});
+        for (auto &s : cs) max_cols = std::max<size_t>(max_cols, (size_t)s.d->main_w + 4 * s.d->perm_ext_w + s.d->prep_w);
         // every matrix writes its opened values into one result buffer; ONE download after the last launch
         // (a host synchronisation per matrix costs more than the small chips' kernels)
         size_t total_vals = 0;
@@ -688,14 +690,22 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
         auto d_all_cols = reinterpret_cast<const uint32_t *const *>(upload(all_ptrs.data(), all_ptrs.size() * 8));
         if (!d_all_cols) return false;
         size_t cols_at = 0;
-        auto open_matrix = [&](const uint32_t *base, uint32_t width, const ChipState &s, Fp4 scale, std::vector<Fp4> *local,
-                               std::vector<Fp4> *next) -> bool {
+        // matrices that share their weights (the prep / main / permutation traces of a chip) are opened by ONE launch over the
+        // concatenation of their columns: note() registers a matrix, open_noted() launches what has been noted
+        size_t group_cols = 0, group_res = 0;
+        uint32_t group_w = 0;
+        auto note = [&](const uint32_t *base, uint32_t width, Fp4 scale, std::vector<Fp4> *local, std::vector<Fp4> *next) -> bool {
             if (cols_at + width > all_ptrs.size() || all_ptrs[cols_at] != (uint64_t)(uintptr_t)base) return fail("prove: internal error, opening order");
-            const uint32_t *const *d_cols = d_all_cols + cols_at;
-            cols_at += width;
-            HIPCHK(launch_open_columns(stream, d_cols, width, s.log_n, d_w, d_partial, d_res + res_off));
+            if (!group_w) { group_cols = cols_at; group_res = res_off; }
             pending.push_back({res_off, width, scale, local, next});
+            cols_at += width;
             res_off += (size_t)width * 2;
+            group_w += width;
+            return true;
+        };
+        auto open_noted = [&](const ChipState &s) -> bool {
+            HIPCHK(launch_open_columns(stream, d_all_cols + group_cols, group_w, s.log_n, d_w, d_partial, d_res + group_res));
+            group_w = 0;
             return true;
         };
         pf.chips.resize(cs.size());
@@ -710,9 +720,10 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
             // trace matrices: point zeta over H
             HIPCHK(launch_open_weights(stream, tabs, zeta, s.log_n, d_w));
             Fp4 scale = (pow(zeta, s.n) - Fp::one()) * ninv;
-            if (s.d->prep_w && !open_matrix(s.prep, s.d->prep_w, s, scale, &o.prep_l, &o.prep_n)) return false;
-            if (!open_matrix(s.main, s.d->main_w, s, scale, &o.main_l, &o.main_n)) return false;
-            if (s.d->perm_ext_w && !open_matrix(s.perm, 4 * s.d->perm_ext_w, s, scale, &o.perm_l, &o.perm_n)) return false;
+            if (s.d->prep_w && !note(s.prep, s.d->prep_w, scale, &o.prep_l, &o.prep_n)) return false;
+            if (!note(s.main, s.d->main_w, scale, &o.main_l, &o.main_n)) return false;
+            if (s.d->perm_ext_w && !note(s.perm, 4 * s.d->perm_ext_w, scale, &o.perm_l, &o.perm_n)) return false;
+            if (!open_noted(s)) return false;
             // quotient chunks: values on s_c * H, opened at zeta  <=>  f(y) = r(s_c y) at y = zeta / s_c
             o.quot.resize(8);
             for (int c = 0; c < 2; c++) {
@@ -720,7 +731,7 @@ bool Engine::prove_shard(const ProvingKey &pk, const std::vector<ChipTrace> &tra
                 Fp4 y = zeta * inv(sc);
                 HIPCHK(launch_open_weights(stream, tabs, y, s.log_n, d_w));
                 Fp4 qs = (pow(y, s.n) - Fp::one()) * ninv;
-                if (!open_matrix(s.quot + (size_t)4 * c * s.n, 4, s, qs, &quot_vals[2 * k + c], nullptr)) return false;
+                if (!note(s.quot + (size_t)4 * c * s.n, 4, qs, &quot_vals[2 * k + c], nullptr) || !open_noted(s)) return false;
             }
         }
         std::vector<Fp4> host_res(res_off);

@@ -3,7 +3,7 @@
 // bls12_381 / secp256k1 crates, reference crates/dkg/Cargo.toml:24-25): what a call computes (the guest machine's
 // semantics) and the rows of the four chips that prove the calls (tools/airgen/rv32.py: build_fp_op, build_fp2_op,
 // build_weierstrass).  What a call computes is host code (the executor); the rows are built on the GPU (one thread per
-// call, k0_bigop_rows_kernel) and, for the CPU-only debug / test entry points, by the same code on the host.
+// call, k0_bigop_cells / _rels / _lookups kernels) and, for the CPU-only debug / test entry points, by the same code on the host.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -167,12 +167,14 @@ DVT_HD Cn operator-(Cn a) { return Cn{a.v ? P - a.v : 0}; }
 DVT_HD Cn operator*(Cn a, Cn b) { return Cn{(uint32_t)((uint64_t)a.v * b.v % P)}; }
 // walks the generated interactions of a chip on one row and counts its byte-table lookups (plain integer counts; on the
 // device the table is the shard's, shared with K0 of the cpu rows: atomics)
+constexpr uint32_t LOOKUP_SLOTS = 4096;   // direct-mapped (key -> count) cache of one workgroup of the lookups kernel: 32 KiB of LDS
 template <class Row>
 struct LookupCtx {
     using T = Cn;
     const Row &r;
     const uint32_t *pubs;
     uint32_t *byte_mult;
+    uint32_t *lds;     // device: keys [LOOKUP_SLOTS] then counts [LOOKUP_SLOTS] of the workgroup's cache, or nullptr
     DVT_HD static T K(uint32_t monty) { return Cn{Fp::raw(monty).canonical()}; }
     DVT_HD static T KI(uint32_t canonical) { return Cn{canonical}; }
     DVT_HD T main(int c, int rot) const { (void)rot; return Cn{r.get(c)}; }   // (the precompile chips' interactions read the local row only)
@@ -182,11 +184,21 @@ struct LookupCtx {
         if (bus != 2 || sign < 0) return;   // bus 2 = byte (tools/airgen/rv32.py BUSES)
         if (!mult.v) return;
         const uint32_t op = vals[0].v, b = vals[2].v, c = vals[3].v;
-        uint32_t *slot = byte_mult + (size_t)(op - 1) * 65536 + (op == B_U16 ? b : (b << 8) | c);
+        const uint32_t key = (op - 1) * 65536u + (op == B_U16 ? b : (b << 8) | c);
 #if defined(__HIP_DEVICE_COMPILE__)
-        atomicAdd(slot, mult.v);
+        // Hot table rows (zero bytes, the small carries) would serialise plain global atomics at the memory side, as in K0 of the
+        // cpu chip (rv32_trace.hip): hits of the workgroup's cache are LDS atomics, conflicts fall through to a global atomic,
+        // the cache is flushed once per workgroup.
+        if (lds) {
+            const uint32_t slot = (key * 2654435761u) >> 20;  // 12 bits
+            const uint32_t old = atomicCAS(&lds[slot], 0xffffffffu, key);
+            if (old == 0xffffffffu || old == key) atomicAdd(&lds[LOOKUP_SLOTS + slot], mult.v);
+            else atomicAdd(byte_mult + key, mult.v);
+        } else {
+            atomicAdd(byte_mult + key, mult.v);
+        }
 #else
-        *slot += mult.v;
+        byte_mult[key] += mult.v;
 #endif
     }
 };
@@ -250,14 +262,22 @@ const char *const ROW_ERROR_TEXT[ROW_N_ERRORS] = {
 // per row: everything but the identities' witnesses), the identities (one wave per row, solve_poly_rel_wave below), then
 // STAGE_LOOKUPS (one thread per row: the byte-table lookups of the finished row).
 enum RowStage { STAGE_ALL = 0, STAGE_CELLS = 1, STAGE_LOOKUPS = 2 };
+// the interactions of group `part` of the chip's LogUp batches (the generator's split, tools/airgen/emit.py split_lparts)
+template <class Air, int LP, class Ctx>
+DVT_HD void lookups_of_part(Ctx &ctx, int part) {
+    if (part == LP) Air::template interactions_part<LP>(ctx);
+    else if constexpr (LP + 1 < Air::N_LPARTS) lookups_of_part<Air, LP + 1>(ctx, part);
+}
+// part < 0: every interaction of the row; otherwise one group (the device walks the groups of a row in parallel)
 template <class Air, int STAGE, class Row>
-DVT_HD RowError finish_row(Row &R, const PolyRelDesc *rels, int nrels, const uint32_t *pubs, uint32_t *byte_mult) {
+DVT_HD RowError finish_row(Row &R, const PolyRelDesc *rels, int nrels, const uint32_t *pubs, uint32_t *byte_mult, int part, uint32_t *lds) {
     if constexpr (STAGE == STAGE_ALL)
         for (int i = 0; i < nrels; i++)
             if (!solve_poly_rel(rels[i], R)) return ROW_NO_WITNESS;
     if constexpr (STAGE != STAGE_CELLS) {
-        LookupCtx<Row> ctx{R, pubs, byte_mult};
-        Air::interactions(ctx);
+        LookupCtx<Row> ctx{R, pubs, byte_mult, lds};
+        if (part < 0) Air::interactions(ctx);
+        else lookups_of_part<Air, 0>(ctx, part);
     }
     return ROW_OK;
 }
@@ -272,7 +292,7 @@ struct WCols {   // column ids of a short-Weierstrass chip
 
 // every cell of the row of call `e` in chip CHIP (the row starts all-zero), its byte-table lookups counted
 template <int CHIP, int STAGE, class Row>
-DVT_HD RowError fill_bigop_row(const BigOpEvent &e, uint32_t shard, Row &R, uint32_t *byte_mult) {
+DVT_HD RowError fill_bigop_row(const BigOpEvent &e, uint32_t shard, Row &R, uint32_t *byte_mult, int part = -1, uint32_t *lds = nullptr) {
     const uint32_t pubs[N_PUBLIC] = {0, 0, 0, shard, 0};   // (the chips read PUB_SHARD only)
     const uint32_t ptrs[2] = {e.a_ptr, e.b_ptr};
     if constexpr (CHIP == RV32_CHIP_FP_OP) {
@@ -288,7 +308,7 @@ DVT_HD RowError fill_bigop_row(const BigOpEvent &e, uint32_t shard, Row &R, uint
         }
         if (!fill_lt(R, RV32_FP_OP_rlt_f_0, RV32_FP_OP_rlt_d_0, RV32_FP_OP_r_0, 48, ConstMod{rels_rv32::fp_op_0_mod})) return ROW_FP_NOT_REDUCED;
         }
-        return finish_row<air_rv32::FpOp, STAGE>(R, rels_rv32::fp_op, rels_rv32::fp_op_n, pubs, byte_mult);
+        return finish_row<air_rv32::FpOp, STAGE>(R, rels_rv32::fp_op, rels_rv32::fp_op_n, pubs, byte_mult, part, lds);
     } else if constexpr (CHIP == RV32_CHIP_U256_MUL) {
         if constexpr (STAGE != STAGE_LOOKUPS) {
         R.put(RV32_U256_MUL_is_real, 1); R.put(RV32_U256_MUL_clk, e.clk);
@@ -309,7 +329,7 @@ DVT_HD RowError fill_bigop_row(const BigOpEvent &e, uint32_t shard, Row &R, uint
             if (!fill_lt(R, RV32_U256_MUL_rlt_f_0, RV32_U256_MUL_rlt_d_0, RV32_U256_MUL_r_0, 32, RowMod<Row>{R, RV32_U256_MUL_m_0})) return ROW_U256_NOT_BELOW;
         }
         }
-        return finish_row<air_rv32::U256Mul, STAGE>(R, rels_rv32::u256_mul, rels_rv32::u256_mul_n, pubs, byte_mult);
+        return finish_row<air_rv32::U256Mul, STAGE>(R, rels_rv32::u256_mul, rels_rv32::u256_mul_n, pubs, byte_mult, part, lds);
     } else if constexpr (CHIP == RV32_CHIP_FP2_OP) {
         if constexpr (STAGE != STAGE_LOOKUPS) {
         const int op = (int)(e.code - SYS_BLS12381_FP2_ADD);
@@ -326,7 +346,7 @@ DVT_HD RowError fill_bigop_row(const BigOpEvent &e, uint32_t shard, Row &R, uint
         if (!fill_lt(R, RV32_FP2_OP_r0lt_f_0, RV32_FP2_OP_r0lt_d_0, RV32_FP2_OP_r0_0, 48, ConstMod{rels_rv32::fp2_op_0_mod}) ||
             !fill_lt(R, RV32_FP2_OP_r1lt_f_0, RV32_FP2_OP_r1lt_d_0, RV32_FP2_OP_r1_0, 48, ConstMod{rels_rv32::fp2_op_0_mod})) return ROW_FP2_NOT_REDUCED;
         }
-        return finish_row<air_rv32::Fp2Op, STAGE>(R, rels_rv32::fp2_op, rels_rv32::fp2_op_n, pubs, byte_mult);
+        return finish_row<air_rv32::Fp2Op, STAGE>(R, rels_rv32::fp2_op, rels_rv32::fp2_op_n, pubs, byte_mult, part, lds);
     } else {
         constexpr bool is_bls = CHIP == RV32_CHIP_BLS_G1;
         if constexpr (STAGE != STAGE_LOOKUPS) {
@@ -348,8 +368,8 @@ DVT_HD RowError fill_bigop_row(const BigOpEvent &e, uint32_t shard, Row &R, uint
         if (add) ok = ok && fill_lt(R, C.x2lt_f, C.x2lt_d, C.x2, L, mod) && fill_lt(R, C.y2lt_f, C.y2lt_d, C.y2, L, mod) && fill_differ(R, C.xne_z, C.x1, C.x2, L);
         if (!ok) return ROW_CURVE_BAD;
         }
-        if constexpr (is_bls) return finish_row<air_rv32::BlsG1, STAGE>(R, rels_rv32::bls_g1, rels_rv32::bls_g1_n, pubs, byte_mult);
-        else return finish_row<air_rv32::SecpK1, STAGE>(R, rels_rv32::secp_k1, rels_rv32::secp_k1_n, pubs, byte_mult);
+        if constexpr (is_bls) return finish_row<air_rv32::BlsG1, STAGE>(R, rels_rv32::bls_g1, rels_rv32::bls_g1_n, pubs, byte_mult, part, lds);
+        else return finish_row<air_rv32::SecpK1, STAGE>(R, rels_rv32::secp_k1, rels_rv32::secp_k1_n, pubs, byte_mult, part, lds);
     }
 }
 }  // namespace
@@ -485,21 +505,36 @@ __device__ static bool solve_poly_rel_wave(const PolyRelDesc &d, DevRow &row, Re
 }
 
 template <int CHIP> struct ChipRels;
-template <> struct ChipRels<RV32_CHIP_FP_OP> { static __device__ const PolyRelDesc *get(int *n) { *n = rels_rv32::fp_op_n; return rels_rv32::fp_op; } };
-template <> struct ChipRels<RV32_CHIP_FP2_OP> { static __device__ const PolyRelDesc *get(int *n) { *n = rels_rv32::fp2_op_n; return rels_rv32::fp2_op; } };
-template <> struct ChipRels<RV32_CHIP_BLS_G1> { static __device__ const PolyRelDesc *get(int *n) { *n = rels_rv32::bls_g1_n; return rels_rv32::bls_g1; } };
-template <> struct ChipRels<RV32_CHIP_SECP_K1> { static __device__ const PolyRelDesc *get(int *n) { *n = rels_rv32::secp_k1_n; return rels_rv32::secp_k1; } };
-template <> struct ChipRels<RV32_CHIP_U256_MUL> { static __device__ const PolyRelDesc *get(int *n) { *n = rels_rv32::u256_mul_n; return rels_rv32::u256_mul; } };
+template <> struct ChipRels<RV32_CHIP_FP_OP> { static constexpr int LPARTS = air_rv32::FpOp::N_LPARTS; static __device__ const PolyRelDesc *get(int *n) { *n = rels_rv32::fp_op_n; return rels_rv32::fp_op; } };
+template <> struct ChipRels<RV32_CHIP_FP2_OP> { static constexpr int LPARTS = air_rv32::Fp2Op::N_LPARTS; static __device__ const PolyRelDesc *get(int *n) { *n = rels_rv32::fp2_op_n; return rels_rv32::fp2_op; } };
+template <> struct ChipRels<RV32_CHIP_BLS_G1> { static constexpr int LPARTS = air_rv32::BlsG1::N_LPARTS; static __device__ const PolyRelDesc *get(int *n) { *n = rels_rv32::bls_g1_n; return rels_rv32::bls_g1; } };
+template <> struct ChipRels<RV32_CHIP_SECP_K1> { static constexpr int LPARTS = air_rv32::SecpK1::N_LPARTS; static __device__ const PolyRelDesc *get(int *n) { *n = rels_rv32::secp_k1_n; return rels_rv32::secp_k1; } };
+template <> struct ChipRels<RV32_CHIP_U256_MUL> { static constexpr int LPARTS = air_rv32::U256Mul::N_LPARTS; static __device__ const PolyRelDesc *get(int *n) { *n = rels_rv32::u256_mul_n; return rels_rv32::u256_mul; } };
 
-// one thread per call: STAGE_CELLS before the identities, STAGE_LOOKUPS after them
-template <int CHIP, int STAGE>
-__global__ void __launch_bounds__(64) k0_bigop_rows_kernel(const BigOpEvent *ev, uint32_t n_ev, uint32_t shard, uint32_t *main, uint32_t log_n, uint32_t *byte_mult,
-                                                           uint32_t *err) {
+// one thread per call: everything but the identities' witnesses
+template <int CHIP>
+__global__ void __launch_bounds__(64) k0_bigop_cells_kernel(const BigOpEvent *ev, uint32_t n_ev, uint32_t shard, uint32_t *main, uint32_t log_n, uint32_t *err) {
     const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_ev) return;
     DevRow R{main, (size_t)1 << log_n, row};
-    const RowError e = fill_bigop_row<CHIP, STAGE>(ev[row], shard, R, byte_mult);
+    const RowError e = fill_bigop_row<CHIP, STAGE_CELLS>(ev[row], shard, R, nullptr);
     if (e != ROW_OK) atomicMax(err, (uint32_t)e);
+}
+// after the identities: one thread per (call, group of LogUp batches) walks the generated interactions of the finished row
+// and counts its byte-table lookups (blockIdx.y = the group: a G1 row has 615 interactions)
+template <int CHIP>
+__global__ void __launch_bounds__(256) k0_bigop_lookups_kernel(const BigOpEvent *ev, uint32_t n_ev, uint32_t shard, uint32_t *main, uint32_t log_n, uint32_t *byte_mult) {
+    __shared__ uint32_t cache[2 * LOOKUP_SLOTS];
+    for (uint32_t s = threadIdx.x; s < LOOKUP_SLOTS; s += blockDim.x) { cache[s] = 0xffffffffu; cache[LOOKUP_SLOTS + s] = 0; }
+    __syncthreads();
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row < n_ev) {
+        DevRow R{main, (size_t)1 << log_n, row};
+        (void)fill_bigop_row<CHIP, STAGE_LOOKUPS>(ev[row], shard, R, byte_mult, (int)blockIdx.y, cache);
+    }
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < LOOKUP_SLOTS; s += blockDim.x)
+        if (cache[s] != 0xffffffffu && cache[LOOKUP_SLOTS + s]) atomicAdd(byte_mult + cache[s], cache[LOOKUP_SLOTS + s]);
 }
 // one wave per call: q and the carries of every identity of the chip
 template <int CHIP>
@@ -519,10 +554,9 @@ __global__ void __launch_bounds__(64) k0_bigop_rels_kernel(uint32_t n_ev, uint32
 
 template <int CHIP>
 static void launch_chip_rows(hipStream_t st, const BigOpEvent *d_ev, uint32_t n_ev, uint32_t shard, uint32_t *d_main, uint32_t log_n, uint32_t *d_byte_mult, uint32_t *d_err) {
-    const unsigned blocks = (n_ev + 63) / 64;
-    k0_bigop_rows_kernel<CHIP, STAGE_CELLS><<<blocks, 64, 0, st>>>(d_ev, n_ev, shard, d_main, log_n, d_byte_mult, d_err);
+    k0_bigop_cells_kernel<CHIP><<<(n_ev + 63) / 64, 64, 0, st>>>(d_ev, n_ev, shard, d_main, log_n, d_err);
     k0_bigop_rels_kernel<CHIP><<<n_ev, 64, 0, st>>>(n_ev, d_main, log_n, d_err);
-    k0_bigop_rows_kernel<CHIP, STAGE_LOOKUPS><<<blocks, 64, 0, st>>>(d_ev, n_ev, shard, d_main, log_n, d_byte_mult, d_err);
+    k0_bigop_lookups_kernel<CHIP><<<dim3((n_ev + 255) / 256, ChipRels<CHIP>::LPARTS), 256, 0, st>>>(d_ev, n_ev, shard, d_main, log_n, d_byte_mult);
 }
 hipError_t launch_k0_bigop_rows(hipStream_t st, int chip, const BigOpEvent *d_ev, uint32_t n_ev, uint32_t shard, uint32_t *d_main, uint32_t log_n,
                                 uint32_t *d_byte_mult, uint32_t *d_err) {
