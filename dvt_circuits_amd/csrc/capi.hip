@@ -738,10 +738,20 @@ static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_buf
         HIP_TRY(p, hipMemcpyAsync(s.d_recs, r.buf, s.n_recs * sizeof(rv32::CycleRec), hipMemcpyHostToDevice, p->copy_stream));
         HIP_TRY(p, hipEventRecord(ev, p->copy_stream));
         uint32_t *d_calls[rv32::N_CHIPS] = {};   // per precompile chip: [error word, padding to 16 bytes, the calls]
+        // what each chip uploads: its calls / events when K0 of the chip runs on the GPU, else the rows the executor thread built
+        auto events_of = [&](int c, const void **src, size_t *bytes) -> bool {
+            if (!r.big.ev[c].empty()) { *src = r.big.ev[c].data(); *bytes = r.big.ev[c].size() * sizeof(rv32::BigOpEvent); return true; }
+            if (c == RV32_CHIP_SHIFT && !r.big.shifts.empty()) { *src = r.big.shifts.data(); *bytes = r.big.shifts.size() * sizeof(rv32::AluEvent); return true; }
+            if (c == RV32_CHIP_MEM_INIT && r.big.mem_rows && !r.big.mem_rows->empty()) { *src = r.big.mem_rows->data(); *bytes = r.big.mem_rows->size() * sizeof(rv32::MemInitRow); return true; }
+            return false;
+        };
         size_t stage_bytes = 0;
         for (int c = 0; c < m->n_chips; c++) {
             if (c == RV32_CHIP_CPU || !s.present[c]) continue;
-            stage_bytes += ((r.big.ev[c].empty() ? r.aux.main[c].size() * 4 : r.big.ev[c].size() * sizeof(rv32::BigOpEvent)) + 255) & ~(size_t)255;
+            const void *src = nullptr;
+            size_t bytes = 0;
+            if (!events_of(c, &src, &bytes)) bytes = r.aux.main[c].size() * 4;
+            stage_bytes += (bytes + 255) & ~(size_t)255;
         }
         if (stage_bytes > p->aux_pinned_bytes) {
             HIP_TRY(p, hipStreamSynchronize(p->eng.stream));
@@ -757,17 +767,19 @@ static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_buf
             stage_at += (bytes + 255) & ~(size_t)255;
             return dst;
         };
+        size_t n_events[rv32::N_CHIPS] = {};
         for (int c = 0; c < m->n_chips; c++) {
             if (c == RV32_CHIP_CPU || !s.present[c]) continue;
-            const std::vector<rv32::BigOpEvent> &calls = r.big.ev[c];
-            if (!calls.empty()) {   // a field / curve precompile chip: K0 of its rows from the calls (after the byte counts are in)
+            const void *src = nullptr;
+            size_t bytes = 0;
+            if (events_of(c, &src, &bytes)) {   // K0 of this chip on the GPU (after the byte counts are in): [error word, padding to 16 bytes, the events]
                 const size_t words = (size_t)m->chips[c].main_w << s.log_n[c];
                 HIP_TRY(p, p->eng.pool.alloc(&s.d_aux[c], words * 4));
                 HIP_TRY(p, hipMemsetAsync(s.d_aux[c], 0, words * 4, p->eng.stream));
-                HIP_TRY(p, p->eng.pool.alloc(&d_calls[c], 16 + calls.size() * sizeof(rv32::BigOpEvent)));
+                HIP_TRY(p, p->eng.pool.alloc(&d_calls[c], 16 + bytes));
                 HIP_TRY(p, hipMemsetAsync(d_calls[c], 0, 16, p->eng.stream));
-                HIP_TRY(p, hipMemcpyAsync(d_calls[c] + 4, staged(calls.data(), calls.size() * sizeof(rv32::BigOpEvent)), calls.size() * sizeof(rv32::BigOpEvent),
-                                          hipMemcpyHostToDevice, p->eng.stream));
+                HIP_TRY(p, hipMemcpyAsync(d_calls[c] + 4, staged(src, bytes), bytes, hipMemcpyHostToDevice, p->eng.stream));
+                n_events[c] = c == RV32_CHIP_SHIFT ? r.big.shifts.size() : c == RV32_CHIP_MEM_INIT ? r.big.mem_rows->size() : r.big.ev[c].size();
                 continue;
             }
             size_t words = r.aux.main[c].size();
@@ -779,9 +791,15 @@ static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_buf
         for (int c = 0; c < m->n_chips; c++) {
             if (!d_calls[c]) continue;
             const size_t words = (size_t)m->chips[c].main_w << s.log_n[c];
-            HIP_TRY(p, rv32::launch_k0_bigop_rows(p->eng.stream, c, reinterpret_cast<const rv32::BigOpEvent *>(d_calls[c] + 4), (uint32_t)r.big.ev[c].size(), s.index,
-                                                  s.d_aux[c], s.log_n[c], s.d_aux[RV32_CHIP_BYTE], d_calls[c]));
-            HIP_TRY(p, launch_to_internal(p->eng.stream, s.d_aux[c], words));
+            if (c == RV32_CHIP_SHIFT) {   // (these two write Montgomery words themselves)
+                HIP_TRY(p, rv32::launch_k0_shift_rows(p->eng.stream, reinterpret_cast<const rv32::AluEvent *>(d_calls[c] + 4), n_events[c], s.d_aux[c], s.log_n[c], s.d_aux[RV32_CHIP_BYTE]));
+            } else if (c == RV32_CHIP_MEM_INIT) {
+                HIP_TRY(p, rv32::launch_k0_mem_init_rows(p->eng.stream, reinterpret_cast<const rv32::MemInitRow *>(d_calls[c] + 4), n_events[c], s.d_aux[c], s.log_n[c], s.d_aux[RV32_CHIP_BYTE]));
+            } else {
+                HIP_TRY(p, rv32::launch_k0_bigop_rows(p->eng.stream, c, reinterpret_cast<const rv32::BigOpEvent *>(d_calls[c] + 4), (uint32_t)n_events[c], s.index,
+                                                      s.d_aux[c], s.log_n[c], s.d_aux[RV32_CHIP_BYTE], d_calls[c]));
+                HIP_TRY(p, launch_to_internal(p->eng.stream, s.d_aux[c], words));
+            }
         }
         HIP_TRY(p, hipStreamSynchronize(p->eng.stream));   // (the staging buffer is reused by the next shard; the error words below)
         for (int c = 0; c < m->n_chips; c++) {

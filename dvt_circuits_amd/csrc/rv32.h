@@ -280,6 +280,65 @@ class Vm {
 void execute(const Program &prog, const std::vector<std::vector<uint8_t>> &stdin_bufs, bool trace, uint64_t max_cycles,
              uint32_t log_shard, ExecResult *res);
 
+// ---- rows of the shift and mem_init chips (K0; Sink: put(col, canonical value); byte(op_index, table_row)) ----------------
+// one SLL / SRL / SRA instruction (tools/airgen/rv32.py build_shift)
+template <class Sink>
+DVT_HD void fill_shift_row(const AluEvent &e, Sink &s) {
+    auto Bt = [](uint32_t w, int i) -> uint32_t { return (w >> (8 * i)) & 0xffu; };
+    const uint32_t sh = e.c & 31, q = sh >> 3, rb = sh & 7, m = 1u << rb, mi = 1u << (8 - rb);
+    const bool left = e.op == ALU_SLL;
+    const uint32_t sgn = e.op == ALU_SRA ? e.b >> 31 : 0;
+    s.put(RV32_SHIFT_is_real, 1);
+    s.put(left ? RV32_SHIFT_is_sll : e.op == ALU_SRL ? RV32_SHIFT_is_srl : RV32_SHIFT_is_sra, 1);
+    s.put(RV32_SHIFT_sh, sh);
+    if (q) s.put(RV32_SHIFT_q_0 + q - 1, 1);
+    s.put(RV32_SHIFT_r_0 + rb, 1);
+    s.put(RV32_SHIFT_sgn, sgn);
+    uint32_t lo[4], hi[4];
+    for (int i = 0; i < 4; i++) {
+        s.put(RV32_SHIFT_a_0 + i, Bt(e.a, i)); s.put(RV32_SHIFT_b_0 + i, Bt(e.b, i)); s.put(RV32_SHIFT_c_0 + i, Bt(e.c, i));
+        if (left) { uint32_t pr = Bt(e.b, i) * m; lo[i] = pr & 0xff; hi[i] = pr >> 8; }
+        else { hi[i] = Bt(e.b, i) >> rb; lo[i] = Bt(e.b, i) & (m - 1); }
+        s.put(RV32_SHIFT_lo_0 + i, lo[i]); s.put(RV32_SHIFT_hi_0 + i, hi[i]);
+    }
+    for (int i = 0; i < 4; i++) {
+        uint32_t t = left ? lo[i] + (i ? hi[i - 1] : 0) : hi[i] + (i < 3 ? lo[i + 1] * mi : sgn * (256 - mi));
+        s.put(RV32_SHIFT_t_0 + i, t);
+        if (!left) s.byte(B_LTU - 1, (lo[i] << 8) | m);
+    }
+    s.byte(B_AND - 1, (Bt(e.c, 0) << 8) | 31);
+    s.byte(B_RANGE - 1, (lo[0] << 8) | lo[1]); s.byte(B_RANGE - 1, (lo[2] << 8) | lo[3]);
+    s.byte(B_RANGE - 1, (hi[0] << 8) | hi[1]); s.byte(B_RANGE - 1, (hi[2] << 8) | hi[3]);
+    if (e.op == ALU_SRA) s.byte(B_MSB - 1, Bt(e.b, 3) << 8);
+}
+// row r of the mem_init table (tools/airgen/rv32.py build_mem_init): the word at rows[r].addr, its initial and final values, the
+// gap to the previous address
+template <class Sink>
+DVT_HD void fill_mem_init_row(const MemInitRow *rows, size_t r, Sink &s) {
+    const MemInitRow m = rows[r];
+    s.put(RV32_MEM_INIT_fts, m.fts); s.put(RV32_MEM_INIT_fsh, m.fsh);
+    s.put(RV32_MEM_INIT_is_img, m.is_img); s.put(RV32_MEM_INIT_is_real, 1);
+    const uint32_t d = r ? m.addr - rows[r - 1].addr - 1 : 0;
+    for (int i = 0; i < 4; i++) {
+        s.put(RV32_MEM_INIT_ab_0 + i, (m.addr >> (8 * i)) & 0xff);
+        s.put(RV32_MEM_INIT_v_0 + i, (m.v >> (8 * i)) & 0xff);
+        s.put(RV32_MEM_INIT_f_0 + i, (m.f >> (8 * i)) & 0xff);
+        s.put(RV32_MEM_INIT_d_0 + i, (d >> (8 * i)) & 0xff);
+    }
+    const uint32_t ws[2] = {m.addr, d};
+    for (int k = 0; k < 2; k++) {
+        const uint32_t w = ws[k];
+        s.byte(B_RANGE - 1, ((w & 0xff) << 8) | ((w >> 8) & 0xff));
+        s.byte(B_RANGE - 1, (((w >> 16) & 0xff) << 8) | (w >> 24));
+    }
+    s.byte(B_LTU - 1, ((m.addr >> 24) << 8) | ((ADDR_LIMIT >> 24) + 1));   // (+ 1: the registers sit at REG_BASE)
+    s.byte(B_LTU - 1, ((d >> 24) << 8) | ((ADDR_LIMIT >> 24) + 1));
+    if (!m.is_img) {
+        s.byte(B_RANGE - 1, ((m.v & 0xff) << 8) | ((m.v >> 8) & 0xff));
+        s.byte(B_RANGE - 1, (((m.v >> 16) & 0xff) << 8) | (m.v >> 24));
+    }
+}
+
 // ---- trace generation (K0) ---------------------------------------------------
 // Sink interface used by fill_cpu_row:  put(col, canonical value);  byte(op_index, table_row);  prog(idx)
 // next_pc: pc of the next retired instruction (the shard's next_pc public value after its last row).
@@ -504,6 +563,10 @@ struct ShardMeta {
 // chips from (launch_k0_bigop_rows)
 struct BigOpBatches {
     std::vector<BigOpEvent> ev[N_CHIPS];
+    // likewise the shift instructions of the shard and (last shard) the rows of the mem_init table: K0 of those chips runs
+    // on the GPU too (launch_k0_shift_rows / launch_k0_mem_init_rows)
+    std::vector<AluEvent> shifts;
+    const std::vector<MemInitRow> *mem_rows = nullptr;
 };
 // device_rows != nullptr (the product path): the field / curve precompile chips get their shape only (present, log_n) and
 // their calls are handed back in *device_rows; nullptr (CPU-only debug / test entry points): their rows are built here
@@ -527,6 +590,10 @@ hipError_t launch_k0_cpu_rows(hipStream_t st, const CycleRec *d_recs, size_t n_r
 hipError_t launch_k0_bigop_rows(hipStream_t st, int chip, const BigOpEvent *d_ev, uint32_t n_ev, uint32_t shard, uint32_t *d_main, uint32_t log_n,
                                 uint32_t *d_byte_mult, uint32_t *d_err);
 const char *bigop_row_error_text(uint32_t code);
+// K0 of the shift / mem_init chips: row i of the zeroed column-major trace (Montgomery words written directly) from event i,
+// byte-table lookups added to d_byte_mult (plain counts) through the same workgroup LDS cache as K0 of the cpu chip
+hipError_t launch_k0_shift_rows(hipStream_t st, const AluEvent *d_ev, size_t n_ev, uint32_t *d_main, uint32_t log_n, uint32_t *d_byte_mult);
+hipError_t launch_k0_mem_init_rows(hipStream_t st, const MemInitRow *d_rows, size_t n_rows, uint32_t *d_main, uint32_t log_n, uint32_t *d_byte_mult);
 #endif
 
 }  // namespace rv32

@@ -1,5 +1,6 @@
 // RV32IM ELF loader, decoder, interpreter and host-side trace assembly (see rv32.h).
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <unordered_map>
@@ -730,6 +731,14 @@ bool build_aux_host(const ShardMeta &S, const std::vector<AluEvent> &alu, const 
     if (lc > 22) { if (err) *err = "shard longer than 2^22 cycles"; return false; }
     for (int c = 0; c < N_CHIPS; c++) { T.present[c] = true; T.main[c].clear(); }
     T.log_n[RV32_CHIP_CPU] = lc;
+    static const bool time_aux = getenv("DVT_TIME_PREPARE") != nullptr;
+    auto t_aux = std::chrono::steady_clock::now();
+    auto lap_aux = [&](const char *what) {
+        if (!time_aux) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[aux] %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_aux).count());
+        t_aux = now;
+    };
     std::vector<uint32_t> byte_mult((size_t)N_BYTE_OPS * 65536, 0);
     HostSink sink{nullptr, 0, 0, byte_mult.data(), nullptr};
     T.present[RV32_CHIP_MEM_INIT] = last;
@@ -738,34 +747,19 @@ bool build_aux_host(const ShardMeta &S, const std::vector<AluEvent> &alu, const 
         const uint32_t lm = ceil_log2(mem_rows->size());
         const size_t nm = (size_t)1 << lm;
         T.log_n[RV32_CHIP_MEM_INIT] = lm;
-        auto &M = T.main[RV32_CHIP_MEM_INIT];
-        M.assign((size_t)RV32_MEM_INIT_MAIN_W * nm, 0);
-        uint32_t prev_addr = 0;
-        for (size_t r = 0; r < mem_rows->size(); r++) {
-            const MemInitRow &m = (*mem_rows)[r];
-            auto put = [&](int col, uint32_t v) { M[(size_t)col * nm + r] = v; };
-            put(RV32_MEM_INIT_fts, m.fts); put(RV32_MEM_INIT_fsh, m.fsh);
-            put(RV32_MEM_INIT_is_img, m.is_img); put(RV32_MEM_INIT_is_real, 1);
-            uint32_t d = r ? m.addr - prev_addr - 1 : 0;
-            for (int i = 0; i < 4; i++) {
-                put(RV32_MEM_INIT_ab_0 + i, (m.addr >> (8 * i)) & 0xff);
-                put(RV32_MEM_INIT_v_0 + i, (m.v >> (8 * i)) & 0xff);
-                put(RV32_MEM_INIT_f_0 + i, (m.f >> (8 * i)) & 0xff);
-                put(RV32_MEM_INIT_d_0 + i, (d >> (8 * i)) & 0xff);
+        if (device_rows) {
+            device_rows->mem_rows = mem_rows;      // K0 of this chip runs on the GPU (launch_k0_mem_init_rows)
+        } else {
+            auto &M = T.main[RV32_CHIP_MEM_INIT];
+            M.assign((size_t)RV32_MEM_INIT_MAIN_W * nm, 0);
+            HostSink ms{M.data(), nm, 0, byte_mult.data(), nullptr};
+            for (size_t r = 0; r < mem_rows->size(); r++) {
+                ms.row = r;
+                fill_mem_init_row(mem_rows->data(), r, ms);
             }
-            for (uint32_t w : {m.addr, d}) {
-                sink.byte(B_RANGE - 1, ((w & 0xff) << 8) | ((w >> 8) & 0xff));
-                sink.byte(B_RANGE - 1, (((w >> 16) & 0xff) << 8) | (w >> 24));
-            }
-            sink.byte(B_LTU - 1, ((m.addr >> 24) << 8) | ((ADDR_LIMIT >> 24) + 1));   // (+ 1: the registers sit at REG_BASE)
-            sink.byte(B_LTU - 1, ((d >> 24) << 8) | ((ADDR_LIMIT >> 24) + 1));
-            if (!m.is_img) {
-                sink.byte(B_RANGE - 1, ((m.v & 0xff) << 8) | ((m.v >> 8) & 0xff));
-                sink.byte(B_RANGE - 1, (((m.v >> 16) & 0xff) << 8) | (m.v >> 24));
-            }
-            prev_addr = m.addr;
         }
     }
+    lap_aux("byte counts zeroed + mem_init rows");
     // shift chip: one row per SLL/SRL/SRA of this shard (absent when the shard does not shift)
     std::vector<AluEvent> shifts, muldivs;
     for (auto &e : alu) (e.op <= ALU_SRA ? shifts : muldivs).push_back(e);
@@ -775,39 +769,19 @@ bool build_aux_host(const ShardMeta &S, const std::vector<AluEvent> &alu, const 
         const uint32_t ls = ceil_log2(shifts.size());
         const size_t ns = (size_t)1 << ls;
         T.log_n[RV32_CHIP_SHIFT] = ls;
-        auto &H = T.main[RV32_CHIP_SHIFT];
-        H.assign((size_t)RV32_SHIFT_MAIN_W * ns, 0);
-        for (size_t r = 0; r < shifts.size(); r++) {
-            const AluEvent &e = shifts[r];
-            auto put = [&](int col, uint32_t v) { H[(size_t)col * ns + r] = v; };
-            auto B = [](uint32_t w, int i) -> uint32_t { return (w >> (8 * i)) & 0xffu; };
-            const uint32_t sh = e.c & 31, q = sh >> 3, rb = sh & 7, m = 1u << rb, mi = 1u << (8 - rb);
-            const bool left = e.op == ALU_SLL;
-            const uint32_t sgn = e.op == ALU_SRA ? e.b >> 31 : 0;
-            put(RV32_SHIFT_is_real, 1);
-            put(left ? RV32_SHIFT_is_sll : e.op == ALU_SRL ? RV32_SHIFT_is_srl : RV32_SHIFT_is_sra, 1);
-            put(RV32_SHIFT_sh, sh);
-            if (q) put(RV32_SHIFT_q_0 + q - 1, 1);
-            put(RV32_SHIFT_r_0 + rb, 1);
-            put(RV32_SHIFT_sgn, sgn);
-            uint32_t lo[4], hi[4];
-            for (int i = 0; i < 4; i++) {
-                put(RV32_SHIFT_a_0 + i, B(e.a, i)); put(RV32_SHIFT_b_0 + i, B(e.b, i)); put(RV32_SHIFT_c_0 + i, B(e.c, i));
-                if (left) { uint32_t pr = B(e.b, i) * m; lo[i] = pr & 0xff; hi[i] = pr >> 8; }
-                else { hi[i] = B(e.b, i) >> rb; lo[i] = B(e.b, i) & (m - 1); }
-                put(RV32_SHIFT_lo_0 + i, lo[i]); put(RV32_SHIFT_hi_0 + i, hi[i]);
+        if (device_rows) {
+            device_rows->shifts = std::move(shifts);     // K0 of this chip runs on the GPU (launch_k0_shift_rows)
+        } else {
+            auto &H = T.main[RV32_CHIP_SHIFT];
+            H.assign((size_t)RV32_SHIFT_MAIN_W * ns, 0);
+            HostSink hs{H.data(), ns, 0, byte_mult.data(), nullptr};
+            for (size_t r = 0; r < shifts.size(); r++) {
+                hs.row = r;
+                fill_shift_row(shifts[r], hs);
             }
-            for (int i = 0; i < 4; i++) {
-                uint32_t t = left ? lo[i] + (i ? hi[i - 1] : 0) : hi[i] + (i < 3 ? lo[i + 1] * mi : sgn * (256 - mi));
-                put(RV32_SHIFT_t_0 + i, t);
-                if (!left) sink.byte(B_LTU - 1, (lo[i] << 8) | m);
-            }
-            sink.byte(B_AND - 1, (B(e.c, 0) << 8) | 31);
-            sink.byte(B_RANGE - 1, (lo[0] << 8) | lo[1]); sink.byte(B_RANGE - 1, (lo[2] << 8) | lo[3]);
-            sink.byte(B_RANGE - 1, (hi[0] << 8) | hi[1]); sink.byte(B_RANGE - 1, (hi[2] << 8) | hi[3]);
-            if (e.op == ALU_SRA) sink.byte(B_MSB - 1, B(e.b, 3) << 8);
         }
     }
+    lap_aux("shift rows");
     // muldiv chip: one row per MULH/MULHSU/DIV/DIVU/REM/REMU of this shard (absent when there is none);
     // witness as tools/airgen/rv32.py:build_muldiv lays it out
     T.present[RV32_CHIP_MULDIV] = !muldivs.empty();
@@ -900,6 +874,7 @@ bool build_aux_host(const ShardMeta &S, const std::vector<AluEvent> &alu, const 
             sink.byte(B_U16 - 1, dl0); sink.byte(B_U16 - 1, dl1);
         }
     }
+    lap_aux("muldiv rows");
     // sha_extend chip: 64 rows per SHA_EXTEND call (absent when the shard makes none)
     T.present[RV32_CHIP_SHA_EXTEND] = !sha_ext.empty();
     T.log_n[RV32_CHIP_SHA_EXTEND] = 0;
@@ -1032,6 +1007,7 @@ bool build_aux_host(const ShardMeta &S, const std::vector<AluEvent> &alu, const 
             }
         }
     }
+    lap_aux("sha rows");
     // field / curve precompile chips: one row per call
     if (!build_bigop_traces(big, S.index, &T, byte_mult.data(), err, device_rows)) return false;
     const uint32_t lp = prep.log_n[RV32_CHIP_PROGRAM];
@@ -1042,6 +1018,7 @@ bool build_aux_host(const ShardMeta &S, const std::vector<AluEvent> &alu, const 
     T.log_n[RV32_CHIP_MEM_IMAGE] = prep.log_n[RV32_CHIP_MEM_IMAGE];
     T.main[RV32_CHIP_MEM_IMAGE].assign((size_t)1 << T.log_n[RV32_CHIP_MEM_IMAGE], 0);
     T.pubs = {S.start_pc % P, S.next_pc % P, last ? (uint32_t)exit_code % P : 0u, S.index, last ? 1u : 0u};
+    lap_aux("precompile shapes, program / byte / mem_image columns");
     return true;
 }
 

@@ -90,6 +90,41 @@ __global__ void __launch_bounds__(256) k0_cpu_rows_kernel(const CycleRec *recs, 
         if (keys[s] != K0_EMPTY && counts[s]) sink.global_add(keys[s], counts[s]);
 }
 
+// K0 of the shift (WHICH = 0: one AluEvent per row) and mem_init (WHICH = 1: one MemInitRow per row) chips: the same sink as the
+// cpu chip's K0 (Montgomery words straight into the column-major trace, lookups through the workgroup's LDS cache).  The
+// host used to build these rows and upload them: 168 MB of mem_init table for the largest legal input against 26 MB of rows.
+template <int WHICH>
+__global__ void __launch_bounds__(256) k0_aux_rows_kernel(const void *events, size_t n_ev, uint32_t *main, uint32_t log_n, uint32_t *byte_mult) {
+    __shared__ uint32_t keys[K0_SLOTS], counts[K0_SLOTS];
+    for (uint32_t s = threadIdx.x; s < K0_SLOTS; s += blockDim.x) { keys[s] = K0_EMPTY; counts[s] = 0; }
+    __syncthreads();
+    DeviceSink sink{main, (size_t)1 << log_n, 0, byte_mult, nullptr, nullptr, keys, counts};
+    const size_t base = (size_t)blockIdx.x * K0_ROWS_PER_BLOCK;
+    for (uint32_t k = 0; k < K0_ROWS_PER_BLOCK / 256; k++) {
+        const size_t r = base + (size_t)k * 256 + threadIdx.x;
+        if (r < n_ev) {
+            sink.row = r;
+            if constexpr (WHICH == 0) fill_shift_row(static_cast<const AluEvent *>(events)[r], sink);
+            else fill_mem_init_row(static_cast<const MemInitRow *>(events), r, sink);
+        }
+    }
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < K0_SLOTS; s += blockDim.x)
+        if (keys[s] != K0_EMPTY && counts[s]) sink.global_add(keys[s], counts[s]);
+}
+hipError_t launch_k0_shift_rows(hipStream_t st, const AluEvent *d_ev, size_t n_ev, uint32_t *d_main, uint32_t log_n, uint32_t *d_byte_mult) {
+    if (!n_ev) return hipSuccess;
+    if (((size_t)1 << log_n) < n_ev) return hipErrorInvalidValue;
+    k0_aux_rows_kernel<0><<<(unsigned)((n_ev + K0_ROWS_PER_BLOCK - 1) / K0_ROWS_PER_BLOCK), 256, 0, st>>>(d_ev, n_ev, d_main, log_n, d_byte_mult);
+    return hipGetLastError();
+}
+hipError_t launch_k0_mem_init_rows(hipStream_t st, const MemInitRow *d_rows, size_t n_rows, uint32_t *d_main, uint32_t log_n, uint32_t *d_byte_mult) {
+    if (!n_rows) return hipSuccess;
+    if (((size_t)1 << log_n) < n_rows) return hipErrorInvalidValue;
+    k0_aux_rows_kernel<1><<<(unsigned)((n_rows + K0_ROWS_PER_BLOCK - 1) / K0_ROWS_PER_BLOCK), 256, 0, st>>>(d_rows, n_rows, d_main, log_n, d_byte_mult);
+    return hipGetLastError();
+}
+
 hipError_t launch_k0_cpu_rows(hipStream_t st, const CycleRec *d_recs, size_t n_recs, uint32_t shard, uint32_t shard_next_pc, const Instr *d_instrs,
                               const uint32_t *d_prog_row, uint32_t *d_cpu, uint32_t log_n, uint32_t *d_byte_mult, uint32_t *d_prog_mult) {
     hipError_t e = hipMemsetAsync(d_cpu, 0, ((size_t)RV32_CPU_MAIN_W << log_n) * 4, st);
