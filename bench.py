@@ -27,7 +27,7 @@ Extra objects on the JSON line (rank 0 prints exactly one line):
                 read N, write 2N words per column) / summed duration of its launches inside one prove, HIP events on
                 the prover's own stream; "alu_bound_exception" carries the Poseidon2 commitment kernels (K2/K3)
   reference_example  BASELINE configs[1] taken literally (tools/bench_reference_guest.py): one proof of the reference's example
-                input through the re-stated finalization guest - ms per whole prove() call, proofs/hour with one and with three
+                input through the re-stated finalization guest - ms per whole prove() call, proofs/hour with one and with eight
                 prover handles on the GPU
   cpu_baseline  the oracle's CPU prover (tests/_oracle_prover.py over oracle/*.c, OpenMP) on two bounded samples of the
                 same guest (smaller iteration constants), production parameters; value = marginal cycles/s
@@ -400,7 +400,7 @@ def main():
             # finalization guest, tests/guests_finalization.py): whole-call latency, and proofs/hour with three handles
             from tools import bench_reference_guest
 
-            out["reference_example"] = bench_reference_guest.measure(reps=5, handles=3)
+            out["reference_example"] = bench_reference_guest.measure(reps=5, handles=8)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(stdin_buf, args.cpu_sizes)
         print(json.dumps(out), flush=True)
