@@ -629,8 +629,11 @@ static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_buf
     const auto t_begin = std::chrono::steady_clock::now();
     auto since_begin = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
 
+    rv32::CurveLog curve_log;
     std::thread fast([&] {
         rv32::Vm vm(prog, &inputs, log_shard);
+        vm.curve_log = &curve_log;
+        struct Close { rv32::CurveLog &l; ~Close() { l.closed.store(true, std::memory_order_release); } } close_log{curve_log};
         size_t pos = 0;
         for (;; pos++) {
             if (pos % stride == first) {
@@ -682,6 +685,7 @@ static int job_prepare(dvt_prover *p, const dvt_pk *pk, const dvt_buf *stdin_buf
                 const auto tw0 = std::chrono::steady_clock::now();
                 {
                     rv32::Vm vm(prog, &inputs, log_shard, snap);
+                    vm.curve_log = &curve_log;
                     snap = rv32::Snapshot();
                     rv32::ShardOut so;
                     so.recs = buf;

@@ -18,7 +18,9 @@
 //   - FENCE / EBREAK / CSR instructions execute but have no chip: a program that retires one
 //     cannot be proven (prove returns DVT_ERR_UNSUPPORTED).  Precompile syscalls are not implemented.
 #pragma once
+#include <atomic>
 #include <cstdint>
+#include <cstring>
 #include <memory>
 #include <string>
 #include <utility>
@@ -211,11 +213,44 @@ struct Cell {
 struct Page { Cell c[1u << PAGE_WORD_BITS]; };
 constexpr uint32_t N_PAGES = 1u << (30 - 2 - PAGE_WORD_BITS);
 
+// Results of the curve precompile calls of one execution in call order.  The prove pipeline executes every shard twice (the
+// sequential fast pass finds the shard boundaries, a traced re-execution produces the records); an affine G1 / secp256k1
+// operation is a field inversion (about 3 us), 80 % of the reference example's execution.  The fast pass appends, the traced
+// passes take what is there and compute themselves when the writer is behind or gone.
+struct CurveLog {
+    static constexpr size_t CHUNK = 4096, MAX_CHUNKS = 1024;   // 4 M calls (600 MB) at most: later calls are recomputed
+    struct Entry { uint32_t r[BIGOP_MAX_WORDS], lam[BIGOP_MAX_WORDS / 2]; };
+    std::unique_ptr<Entry[]> chunks[MAX_CHUNKS];
+    std::atomic<size_t> published{0};
+    std::atomic<bool> closed{false};    // the writer has finished, trapped or filled the log
+    void append(size_t idx, const uint32_t *r, const uint32_t *lam) {   // writer only; idx == published
+        if (idx != published.load(std::memory_order_relaxed) || idx >= CHUNK * MAX_CHUNKS) { closed.store(true, std::memory_order_release); return; }
+        if (idx % CHUNK == 0) chunks[idx / CHUNK].reset(new Entry[CHUNK]);
+        Entry &e = chunks[idx / CHUNK][idx % CHUNK];
+        memcpy(e.r, r, sizeof e.r); memcpy(e.lam, lam, sizeof e.lam);
+        published.store(idx + 1, std::memory_order_release);
+    }
+    bool fetch(size_t idx, uint32_t *r, uint32_t *lam) const {
+        // (the writer is never blocked while a reader of an EARLIER call waits: it only pauses at shard boundaries, after
+        // everything of the shards before has been published)
+        while (published.load(std::memory_order_acquire) <= idx) {
+            if (closed.load(std::memory_order_acquire) && published.load(std::memory_order_acquire) <= idx) return false;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        const Entry &e = chunks[idx / CHUNK][idx % CHUNK];
+        memcpy(r, e.r, sizeof e.r); memcpy(lam, e.lam, sizeof e.lam);
+        return true;
+    }
+};
+
 struct Snapshot {
     Cell regs[32];
     uint32_t pc = 0, shard = 1;
     uint64_t cycles = 0;
     size_t next_input = 0;
+    size_t curve_index = 0;   // curve precompile calls retired so far (position in a CurveLog)
     std::vector<std::pair<uint32_t, std::shared_ptr<Page>>> pages;
 };
 
@@ -251,6 +286,10 @@ class Vm {
     std::string error, unsupported_what;
     std::vector<uint8_t> public_values, stdout_bytes;
     uint32_t committed[8] = {}, committed_mask = 0;
+    // optional (the prove pipeline): the fast pass (run_shard(false, ...)) appends the results of its curve precompile calls,
+    // traced passes read them
+    CurveLog *curve_log = nullptr;
+    size_t curve_index = 0;
 
   private:
     Cell regs[32];

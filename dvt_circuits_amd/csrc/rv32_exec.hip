@@ -210,6 +210,7 @@ Vm::Vm(const Program &p, const std::vector<std::vector<uint8_t>> *in, uint32_t l
 Vm::Vm(const Program &p, const std::vector<std::vector<uint8_t>> *in, uint32_t ls, const Snapshot &s)
     : prog(p), pc(s.pc), shard(s.shard), log_shard(ls), cycles(s.cycles), collect_output(false), stdin_bufs(in), next_input(s.next_input),
       holders(N_PAGES), raw(N_PAGES, nullptr), own(N_PAGES, 0) {
+    curve_index = s.curve_index;
     for (int i = 0; i < 32; i++) regs[i] = s.regs[i];
     for (auto &kv : s.pages) { holders[kv.first] = kv.second; raw[kv.first] = kv.second.get(); alloc_pages.push_back(kv.first); }
 }
@@ -227,7 +228,7 @@ void Vm::make_own(uint32_t pg) {
 Snapshot Vm::snapshot() {
     Snapshot s;
     for (int i = 0; i < 32; i++) s.regs[i] = regs[i];
-    s.pc = pc; s.shard = shard; s.cycles = cycles; s.next_input = next_input;
+    s.pc = pc; s.shard = shard; s.cycles = cycles; s.next_input = next_input; s.curve_index = curve_index;
     s.pages.reserve(alloc_pages.size());
     for (uint32_t pg : alloc_pages) s.pages.emplace_back(pg, holders[pg]);
     for (uint32_t pg : owned_pages) own[pg] = 0;   // from now on shared with the snapshot
@@ -523,7 +524,18 @@ L_ECALL: {
         // values first (nothing is stamped if the call traps), then the accesses: b at clk + 2, a at clk + 3
         for (int k = 0; k < bi.words_b; k++) { const Cell *cl = peek(a1 + 4 * k); lev.b[k] = cl ? cl->val : 0; }
         for (int k = 0; k < bi.words_a; k++) { const Cell *cl = peek(c + 4 * k); lev.a[k] = cl ? cl->val : 0; }
-        why = bigop_compute(b, lev.a, lev.b, lev.r, lev.lam);
+        if (curve_log && (bi.chip == RV32_CHIP_BLS_G1 || bi.chip == RV32_CHIP_SECP_K1)) {
+            // (results are a function of the operands: whoever computes them, the fast pass or this one, they are the same)
+            const size_t idx = curve_index++;
+            if (TRACE) {
+                if (!curve_log->fetch(idx, lev.r, lev.lam)) why = bigop_compute(b, lev.a, lev.b, lev.r, lev.lam);
+            } else {
+                why = bigop_compute(b, lev.a, lev.b, lev.r, lev.lam);
+                if (!why) curve_log->append(idx, lev.r, lev.lam);
+            }
+        } else {
+            why = bigop_compute(b, lev.a, lev.b, lev.r, lev.lam);
+        }
         if (why) goto trapped;
         {
             Cell &r11 = regs[REG_A1];
