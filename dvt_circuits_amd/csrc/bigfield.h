@@ -10,7 +10,7 @@ namespace dvt {
 template <int N>
 struct MontField {
     using u128 = unsigned __int128;
-    uint64_t p[N], r2[N], one[N], pm2[N], n0;
+    uint64_t p[N], r2[N], r3[N], one[N], pm2[N], n0;
 
     explicit MontField(const uint64_t (&modulus)[N]) {
         memcpy(p, modulus, sizeof p);
@@ -24,6 +24,7 @@ struct MontField {
         memcpy(one, t, sizeof t);
         for (int i = 0; i < 64 * N; i++) dbl(t);
         memcpy(r2, t, sizeof t);
+        mul(r3, r2, r2);   // R^3 (needs n0 and p: set above)
         memcpy(pm2, p, sizeof p);
         pm2[0] -= 2;    // (p is odd and > 2: no borrow)
     }
@@ -98,12 +99,15 @@ struct MontField {
             if (a[i]) return 64 * i + 64 - __builtin_clzll(a[i]);
         return 0;
     }
-    // t = (x f + y g) as N + 1 limbs, two's complement (|f|, |g| <= 2^31)
+    // t = (x f + y g) as N + 1 limbs, two's complement (|f|, |g| <= 2^31): unsigned 64 x 64 -> 128 products of the magnitudes,
+    // signs applied to the products (a signed 128 x 64 product costs two multiplications each)
     static void lin2(uint64_t *t, const uint64_t *x, int64_t f, const uint64_t *y, int64_t g) {
+        const uint64_t af = (uint64_t)(f < 0 ? -f : f), ag = (uint64_t)(g < 0 ? -g : g);
+        const bool nf = f < 0, ng = g < 0;
         __int128 carry = 0;
         for (int i = 0; i < N; i++) {
-            // x_i, y_i are unsigned 64-bit: split the signed products through unsigned 128-bit arithmetic
-            const __int128 acc = (__int128)(u128)x[i] * f + (__int128)(u128)y[i] * g + carry;
+            const __int128 p1 = (__int128)((u128)x[i] * af), p2 = (__int128)((u128)y[i] * ag);   // (< 2^95: positive)
+            const __int128 acc = carry + (nf ? -p1 : p1) + (ng ? -p2 : p2);
             t[i] = (uint64_t)acc;
             carry = acc >> 64;
         }
@@ -143,14 +147,14 @@ struct MontField {
             }
             int64_t f0 = 1, g0 = 0, f1 = 0, g1 = 1;
             for (int j = 0; j < 31; j++) {
-                if (xa & 1) {
-                    if (xa < xb) {
-                        uint64_t tx = xa; xa = xb; xb = tx;
-                        int64_t tf = f0; f0 = f1; f1 = tf;
-                        int64_t tg = g0; g0 = g1; g1 = tg;
-                    }
-                    xa -= xb; f0 -= f1; g0 -= g1;
-                }
+                // branch-free (the conditions are data-dependent coin flips: a mispredicted branch costs more than the masks):
+                // odd -> (swap when xa < xb), subtract; then halve
+                const uint64_t odd = (uint64_t)0 - (xa & 1), sw = odd & ((uint64_t)0 - (uint64_t)(xa < xb));
+                const uint64_t tx = (xa ^ xb) & sw;
+                xa ^= tx; xb ^= tx;
+                const int64_t tf = (f0 ^ f1) & (int64_t)sw, tg = (g0 ^ g1) & (int64_t)sw;
+                f0 ^= tf; f1 ^= tf; g0 ^= tg; g1 ^= tg;
+                xa -= xb & odd; f0 -= f1 & (int64_t)odd; g0 -= g1 & (int64_t)odd;
                 xa >>= 1;
                 f1 <<= 1; g1 <<= 1;
             }
@@ -183,9 +187,8 @@ struct MontField {
     }
     void inv(uint64_t *o, const uint64_t *a) const {   // Montgomery in, Montgomery out
         uint64_t c[N];
-        from_mont(c, a);
-        inv_canonical(c, c);
-        to_mont(o, c);
+        inv_canonical(c, a);      // a holds x R: c = x^-1 R^-1
+        mul(o, c, r3);            // x^-1 R^-1 R^3 R^-1 = x^-1 R
     }
     void inv_fermat(uint64_t *o, const uint64_t *a) const {   // Montgomery in, Montgomery out: a^(p-2) (the cross-check of inv)
         uint64_t r[N], b[N];

@@ -26,7 +26,7 @@ template <int N> int run(const uint64_t (&P)[N], const char *name) {
     a[N - 1] &= (P[N - 1] >> 1);
     F.to_mont(am, a);
     auto t0 = std::chrono::steady_clock::now();
-    for (int i = 0; i < 20000; i++) { F.inv(o, am); am[0] ^= o[0] & 1; }
+    for (int i = 0; i < 20000; i++) { F.inv(o, am); for (int k = 0; k < N; k++) am[k] = o[k]; am[0] ^= (uint64_t)i + 2; if (F.cmp(am, F.p) >= 0) am[N - 1] >>= 1; }   // (a different operand every time: the branches of the algorithm are data-dependent)
     auto t1 = std::chrono::steady_clock::now();
     for (int i = 0; i < 2000; i++) { F.inv_fermat(o, am); am[0] ^= o[0] & 1; }
     auto t2 = std::chrono::steady_clock::now();
