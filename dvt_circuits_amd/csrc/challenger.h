@@ -35,6 +35,19 @@ struct Challenger {
         for (int i = 0; i < 4; i++) observe(x.c[i]);
     }
     void observe_u32(uint32_t v) { observe(Fp::from_canonical(v % P)); }
+    // The values a chip's matrix opens to at one point enter the transcript as ONE sponge digest of the vector (nothing for an
+    // empty vector), not element by element: a shard with precompile chips opens ~5 000 columns at two points, and absorbing
+    // ~20 k elements is ~2 500 SEQUENTIAL permutations the GPU would wait for; the digests of different vectors are independent
+    // chains (the prover hashes them on a few host threads, engine.hip).
+    static Digest hash_values(const std::vector<Fp4> &v) {
+        Sponge sp;
+        for (auto &x : v)
+            for (int i = 0; i < 4; i++) sp.absorb(x.c[i]);
+        return sp.finish();
+    }
+    void observe_values(const std::vector<Fp4> &v) {
+        if (!v.empty()) observe(hash_values(v));
+    }
     Fp sample() {
         if (!input.empty() || output.empty()) duplex();
         Fp r = output.back();

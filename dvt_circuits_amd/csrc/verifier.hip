@@ -134,8 +134,7 @@ std::string verify_shard(const VerifyingKey &vk, const ShardProof &pf, const Sta
     ch.observe(pf.quot_root);
     Fp4 zeta = ch.sample_ext();
     for (auto &o : pf.chips)
-        for (auto *v : {&o.prep_l, &o.prep_n, &o.main_l, &o.main_n, &o.perm_l, &o.perm_n, &o.quot})
-            for (auto &x : *v) ch.observe(x);
+        for (auto *v : {&o.prep_l, &o.prep_n, &o.main_l, &o.main_n, &o.perm_l, &o.perm_n, &o.quot}) ch.observe_values(*v);
 
     // ---- constraints at zeta
     int max_arity = 1, max_folded = 1;

@@ -48,6 +48,22 @@ class Challenger:
             if len(self.inp) == 8:
                 self.duplex()
 
+    def observe_values(self, vals):
+        """the values a matrix opens to at one point enter the transcript as one sponge digest (nothing for an empty list):
+        dvt_circuits_amd/csrc/challenger.h observe_values"""
+        flat = [int(x) % P for v in vals for x in v]
+        if not flat:
+            return
+        st, pos = [0] * 16, 0
+        for x in flat:
+            st[pos] = x
+            pos += 1
+            if pos == 8:
+                st, pos = self.orc.permute(np.array(st, np.uint32)).tolist(), 0
+        if pos:
+            st = self.orc.permute(np.array(st, np.uint32)).tolist()
+        self.observe(st[:8])
+
     def sample(self):
         if self.inp or not self.out:
             self.duplex()
@@ -257,8 +273,7 @@ def prove_shard(machine, chips, pubs, num_queries, pow_bits, perm_challenges=Non
         c["open"]["quot"] = evals(c["quot"][:4], c["log_n"], G, zeta) + evals(c["quot"][4:], c["log_n"], s1, zeta)
     for c in cs:
         for k in ("prep_l", "prep_n", "main_l", "main_n", "perm_l", "perm_n", "quot"):
-            for v in c["open"][k]:
-                ch.observe(v)
+            ch.observe_values(c["open"][k])
     lap("openings")
     # 5. FRI input
     alpha_fri = ch.sample_ext()
