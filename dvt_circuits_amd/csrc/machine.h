@@ -47,6 +47,7 @@ struct MachineDesc {
     const ChipDesc *chips;
 };
 
+constexpr int RV32_FIRST_WIDE_CHIP = 9;   // fp_op: the first of the field / curve precompile chips (gen/rv32_cols.h RV32_CHIP_FP_OP)
 const MachineDesc *machine_toy();
 const MachineDesc *machine_rv32();
 const MachineDesc *machine_by_name(const char *name);

@@ -12,8 +12,18 @@
 #pragma clang optimize on
 #endif
 
+// The chips are instantiated in two translation units compiled side by side (this file: the cpu machine proper; the five
+// field / curve precompile chips with their part-parallel kernels in machine_rv32_wide.hip): one unit took seven minutes.
 namespace dvt {
-#define DVT_X(i, A) make_chip_desc<A>(),
+ChipDesc rv32_wide_chip_desc(int chip);   // machine_rv32_wide.hip
+namespace {
+template <int I, class A>
+ChipDesc chip_desc_here() {
+    if constexpr (I < RV32_FIRST_WIDE_CHIP) return make_chip_desc<A>();
+    else return rv32_wide_chip_desc(I);
+}
+}  // namespace
+#define DVT_X(i, A) chip_desc_here<i, A>(),
 static const ChipDesc rv32_chips[] = {DVT_AIR_RV32_CHIPS(DVT_X)};
 #undef DVT_X
 static const MachineDesc rv32_machine = {"rv32", air_rv32::N_CHIPS, rv32_chips};
