@@ -260,7 +260,7 @@ const char *const ROW_ERROR_TEXT[ROW_N_ERRORS] = {
 
 // STAGE_ALL: the whole row by one thread (host).  On the device the row is built in three launches: STAGE_CELLS (one thread
 // per row: everything but the identities' witnesses), the identities (one wave per row, solve_poly_rel_wave below), then
-// STAGE_LOOKUPS (one thread per row: the byte-table lookups of the finished row).
+// STAGE_LOOKUPS (one thread per row and group of LogUp batches: the byte-table lookups of the finished row).
 enum RowStage { STAGE_ALL = 0, STAGE_CELLS = 1, STAGE_LOOKUPS = 2 };
 // the interactions of group `part` of the chip's LogUp batches (the generator's split, tools/airgen/emit.py split_lparts)
 template <class Air, int LP, class Ctx>
