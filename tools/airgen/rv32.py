@@ -434,8 +434,8 @@ def build_cpu():
     ch.assert_zero(ec * (is_commit * u_clk))
     ch.assert_zero(ec * (is_commit * u_sh))
     ch.send("sys", b + c + mv + [u_clk, u_sh], sys_m)
-    ch.quotient_parts = 4
-    ch.logup_parts = 5
+    ch.quotient_parts = 3
+    ch.logup_parts = 4
     return ch
 
 
